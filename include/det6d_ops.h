@@ -1,0 +1,225 @@
+/*
+ * det6d_ops.h — C ABI of libdet6d_hip.so, the MI355X (gfx950) drop-in for the two compiled
+ * extension modules on the Det6D inference path of HITSZ-NRSL/De6D:
+ *
+ *   pointnet2_batch_cuda  (core/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:11-30)
+ *   iou3d_nms_cuda        (core/pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17)
+ *
+ * Conventions (they replace the reference's at::Tensor / exit(-1) conventions,
+ * ball_query.cpp:17-29, sampling_gpu.cu:261-265):
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all buffers (outputs and scratch), exactly like the reference
+ *     (pointnet2_utils.py:25-26,294,323-324; iou3d_nms_utils.py:97);
+ *   - all tensors are dense, row-major, fp32 / int32 unless stated;
+ *   - `stream` is a hipStream_t (NULL = the null stream); calls are asynchronous and
+ *     graph-capturable unless documented otherwise;
+ *   - return value: DET6D_OK (0) or a negative DET6D_E* code; nothing ever calls exit().
+ *
+ * The same signatures with the prefix `det6d_oracle_` and HOST pointers (no stream argument)
+ * are exported by oracle/libdet6d_oracle.so, the CPU restatement used only by tests.
+ */
+#ifndef DET6D_OPS_H
+#define DET6D_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t *det6d_stream_t; /* == hipStream_t */
+
+#define DET6D_OK 0
+#define DET6D_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
+#define DET6D_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after the launch */
+#define DET6D_ENOGPU (-3)   /* no HIP device visible */
+
+/* library identification: returns a static string "det6d-hip gfx950 <abi-version>" */
+const char *det6d_version(void);
+/* last HIP error string seen by this library on the calling thread ("" if none) */
+const char *det6d_last_error(void);
+
+/* ------------------------------------------------------------------ sampling ------------- */
+
+/* D-FPS. Replaces farthest_point_sampling_wrapper(b,n,m,xyz,temp,idx)
+ * (sampling.cpp:40-50 -> sampling_gpu.cu:101-266).
+ *   xyz (B,N,3) f32; temp (B,N) f32 scratch, caller pre-fills 1e10, clobbered; idx (B,M) i32.
+ * idx[:,0] = 0; ties resolved exactly like the reference's strided scan + smem tree. */
+int det6d_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, det6d_stream_t stream);
+
+/* S-FPS. Replaces furthest_point_sampling_weights_wrapper(b,n,m,xyz,weights,temp,idx)
+ * (sampling.cpp:66-79 -> sampling_gpu.cu:419-585).  weights (B,N) f32. */
+int det6d_fps_weights(int b, int n, int m, const float *xyz, const float *weights, float *temp,
+                      int *idx, det6d_stream_t stream);
+
+/* Replaces gather_points_wrapper(b,c,n,npoints,points,idx,out) (sampling_gpu.cu:16-52).
+ *   points (B,C,N); idx (B,M) i32; out (B,C,M). */
+int det6d_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                        float *out, det6d_stream_t stream);
+
+/* Replaces gather_points_grad_wrapper (sampling_gpu.cu:54-90): grad_points (B,C,N) += scatter. */
+int det6d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                             const int *idx, float *grad_points, det6d_stream_t stream);
+
+/* ------------------------------------------------------------------ ball query ----------- */
+
+/* Replaces ball_query_wrapper (ball_query_gpu.cu:15-51,157-176).
+ *   new_xyz (B,M,3); xyz (B,N,3); idx (B,M,nsample) i32, caller zero-fills. */
+int det6d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const float *xyz, int *idx, det6d_stream_t stream);
+
+/* Replaces ball_query_cnt_wrapper (ball_query_gpu.cu:93-153). idx_cnt (B,M) i32. */
+int det6d_ball_query_cnt(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                         const float *xyz, int *idx_cnt, int *idx, det6d_stream_t stream);
+
+/* Replaces ball_query_dilated_wrapper (ball_query_gpu.cu:53-91,178-198). */
+int det6d_ball_query_dilated(int b, int n, int m, float radius_in, float radius_out, int nsample,
+                             const float *new_xyz, const float *xyz, int *idx_cnt, int *idx,
+                             det6d_stream_t stream);
+
+/* ------------------------------------------------------------------ grouping ------------- */
+
+/* Replaces group_points_wrapper (group_points_gpu.cu:53-92).
+ *   points (B,C,N); idx (B,npoints,nsample) i32; out (B,C,npoints,nsample). */
+int det6d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, det6d_stream_t stream);
+
+/* Replaces group_points_grad_wrapper (group_points_gpu.cu:14-51). */
+int det6d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                            const int *idx, float *grad_points, det6d_stream_t stream);
+
+/* ------------------------------------------------------------------ interpolation -------- */
+
+/* Replaces three_nn_wrapper(b,n,m,unknown,known,dist2,idx) (interpolate_gpu.cu:16-82).
+ *   unknown (B,n,3); known (B,m,3); dist2 (B,n,3) f32; idx (B,n,3) i32. */
+int det6d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                   int *idx, det6d_stream_t stream);
+
+/* Replaces three_interpolate_wrapper(b,c,m,n,points,idx,weight,out) (interpolate_gpu.cu:84-124).
+ *   points (B,C,m); idx (B,n,3); weight (B,n,3); out (B,C,n). */
+int det6d_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                            const float *weight, float *out, det6d_stream_t stream);
+
+/* Replaces three_interpolate_grad_wrapper (interpolate_gpu.cu:127-170). */
+int det6d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                 const float *weight, float *grad_points, det6d_stream_t stream);
+
+/* ------------------------------------------------------------------ rotated IoU / NMS ---- */
+
+/* Replaces boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d_nms.cpp:49-88,
+ * iou3d_nms_kernel.cu:236-265).  boxes (K,7) [x,y,z,dx,dy,dz,heading]; out (num_a,num_b). */
+int det6d_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                            float *ans_overlap, det6d_stream_t stream);
+int det6d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                        float *ans_iou, det6d_stream_t stream);
+
+/* number of uint64 words the mask scratch of det6d_nms* needs: K * ceil(K/64) */
+int64_t det6d_nms_mask_words(int boxes_num);
+
+/* Rotated-BEV NMS, fully on device. Replaces nms_gpu (iou3d_nms.cpp:90-136 +
+ * iou3d_nms_kernel.cu:267-311): suppression bit-matrix by one wave64 ballot per 64x64 tile,
+ * then the greedy scan by a single wave, no host round trip.
+ *   boxes (K,7) sorted by descending score; mask (det6d_nms_mask_words(K)) u64 scratch;
+ *   keep (K) i64 DEVICE, first *num_keep entries valid; num_keep (1) i32 DEVICE. */
+int det6d_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask, int64_t *keep,
+              int *num_keep, det6d_stream_t stream);
+
+/* Axis-aligned variant. Replaces nms_normal_gpu (iou3d_nms.cpp:139-186, kernel :313-372). */
+int det6d_nms_normal(int boxes_num, const float *boxes, float thresh, uint64_t *mask,
+                     int64_t *keep, int *num_keep, det6d_stream_t stream);
+
+/* Reference-shaped convenience for the pybind-style `nms_gpu(boxes, keep_cpu, thr) -> num`:
+ * runs det6d_nms on `stream`, synchronises it and copies keep to HOST memory.
+ * NOT graph-capturable (it blocks, like the reference does). */
+int det6d_nms_to_host(int boxes_num, const float *boxes, float thresh, int64_t *keep_host,
+                      int normal, det6d_stream_t stream);
+
+/* ------------------------------------------------------------------ fused engine ops ----- */
+/* These have no 1:1 reference symbol; they implement the Python-level hot loop of
+ * _PointnetSAModuleFSBase.forward (pointnet2_modules.py:462-494) and
+ * PointHeadBox6DVote.forward (point_head_box6d_vote.py:794-903) as fused kernels. */
+
+/* Pack the reference's flat `points (B*N, 1+3+C)` rows [b,x,y,z,feat..] into the engine's
+ * point-major row layout `rows (B,N,ld)` = [x,y,z,feat..,0 pad], ld % 4 == 0.
+ * (PointNet2FSMSG.break_up_pc + view/permute, pointnet2_backbone.py:193-224.) */
+int det6d_pack_points(int total, int cin, const float *points, int ld, float *rows,
+                      det6d_stream_t stream);
+
+/* rows_out[b,j,0:ncol] = rows_in[b, idx[b,j], 0:ncol]   (point-major gather; xyz is ncol=3) */
+int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol, const float *rows_in,
+                      const int *idx, float *rows_out, det6d_stream_t stream);
+
+/* Fused pointwise layer   Y = act(A' * W + shift)  on fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ * products accumulated in ascending-k order in one fp32 accumulator per output
+ * (bit-identical to the oracle's fmaf chain).
+ *
+ *   mode A' source:
+ *     DET6D_A_ROWS    A'[r][k] = a[r*lda + k]
+ *     DET6D_A_GROUPED r = (b, j, s): p = idx[(b*m + j)*ns + s];
+ *                     A'[r][k] = a[(b*n + p)*lda + k] - (k < 3 ? ctr[(b*m + j)*ldctr + k] : 0)
+ *                     (QueryAndGroup: grouped_xyz -= new_xyz, cat([xyz, feat]);
+ *                      pointnet2_utils.py:449-455)
+ *   W (K,ldw) row-major with BN folded in, shift (N) = folded BN shift or conv bias (may be NULL),
+ *   act: 0 none, 1 ReLU.
+ *   pool == 0: y[r*ldy + col0 + c]                      (R rows)
+ *   pool == ns: y[(r/ns)*ldy + col0 + c] = max over the ns rows of a group of
+ *               act(..) * (cnt[r/ns] > 0)   (mask then max_pool2d, pointnet2_modules.py:465-472)
+ */
+#define DET6D_A_ROWS 0
+#define DET6D_A_GROUPED 1
+typedef struct det6d_linear_args {
+  int mode;          /* DET6D_A_ROWS / DET6D_A_GROUPED */
+  int rows;          /* R: number of A' rows (= b*m*ns in grouped mode) */
+  int k;             /* reduction length (columns of A' actually used) */
+  int ncols;         /* N: output channels */
+  const float *a; int lda;
+  const float *w; int ldw;
+  const float *shift;      /* (N) or NULL */
+  int act;                 /* 0 none, 1 relu */
+  float *y; int ldy; int col0;
+  /* grouped mode only */
+  int n, m, ns;            /* points per scene, centres per scene, samples per centre */
+  const int *idx;          /* (B,m,ns) */
+  const float *ctr; int ldctr; /* (B,m,ldctr) centre rows, first 3 columns are xyz */
+  /* pooling epilogue */
+  int pool;                /* 0 or ns */
+  const int *cnt;          /* (B*m) hit counts or NULL (no mask) */
+} det6d_linear_args;
+int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
+
+/* s-fps weights: w[i] = sigmoid(score[i]) ** gamma  (pointnet2_modules.py:415-419) */
+int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,
+                      det6d_stream_t stream);
+
+/* vote_xyz = cand_xyz + clamp(offset, -range, +range)
+ * (point_head_box6d_vote.py:816-821).  off (R,ldo) first 3 cols; cand (R,ldc) first 3 cols;
+ * out vote (R,ldv) first 3 cols; also writes the clamped offsets to off_out (R,3) if non-NULL */
+int det6d_vote_points(int rows, const float *off, int ldo, const float *cand, int ldc,
+                      float rx, float ry, float rz, float *vote, int ldv, float *off_out,
+                      det6d_stream_t stream);
+
+/* PointBinResidual6DCoder.decode_torch with use_mean_size = False
+ * (box_coder_utils.py:589-603,622-680,723-737).
+ *   code (R,ldcode) = 6 offsets + nbin yaw logits + nbin yaw residuals + (ground_aware ? 2 : 1);
+ *   pts (R,ldp) first 3 cols; boxes (R,9) = [x,y,z,dx,dy,dz,rz,ry,rx]. */
+int det6d_decode_boxes(int rows, int nbin, int ground_aware, int minus, float threshold_rad,
+                       float factor_rad, const float *code, int ldcode, const float *pts, int ldp,
+                       float *boxes, det6d_stream_t stream);
+
+/* Per-scene post-processing (Detector3DTemplate.post_processing eval branch +
+ * class_agnostic_nms + nms_gpu: detector3d_template.py:178-284, model_nms_utils.py:6-25,
+ * iou3d_nms_utils.py:84-99), one workgroup per scene, no host sync:
+ *   cls (B*P,ncls) logits; boxes (B*P,9); per scene: sigmoid, max over classes, score >= thr,
+ *   stable descending sort, top pre_max, rotated NMS (dims 0..6) at nms_thr, first post_max.
+ * Outputs (device): out_boxes (B,post_max,9), out_scores (B,post_max), out_labels (B,post_max)
+ * i32 1-based, out_index (B,post_max) i32 = index of the kept box inside its scene, out_count (B).
+ * P <= 1024. Equal scores are ordered by ascending original index (the reference uses an
+ * unstable torch sort there). */
+int det6d_postprocess(int b, int p, int ncls, const float *cls, const float *boxes, float score_thr,
+                      int pre_max, int post_max, float nms_thr, float *out_boxes, float *out_scores,
+                      int *out_labels, int *out_index, int *out_count, det6d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DET6D_OPS_H */

@@ -1,0 +1,787 @@
+/*
+ * det6d_oracle.c — CPU restatement of the Det6D inference hot path of HITSZ-NRSL/De6D.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (de6d_amd/) never does.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - rotated IoU / NMS: pinned against the reference's own iou3d_cpu.cpp compiled into
+ *     oracle/_ref (tests/test_oracle_ref.py) and against fixtures generated from it;
+ *   - box decode and the whole-model glue: pinned against golden vectors produced by importing the
+ *     reference's Python (tests/golden/make_golden.py);
+ *   - FPS / ball query / grouping / three_nn: the reference has NO CPU implementation and no
+ *     tests for them, and its CUDA cannot run here: parity unpinned at the reference level.
+ *     They are restated line by line from the .cu files cited at each function.
+ *
+ * Arithmetic conventions shared with the HIP kernels (compile both with -ffp-contract=off):
+ *   - squared distances use the contraction LLVM's DAG combiner (and therefore NVVM) produces
+ *     for `dx*dx + dy*dy + dz*dz`:  fma(dz,dz, fma(dx,dx, dy*dy));
+ *   - rotated-box geometry follows iou3d_cpu.cpp as built for x86-64: no contraction;
+ *   - transcendentals come from include/det6d_math.h.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/det6d_math.h"
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+static inline float sqdist(float dx, float dy, float dz) {
+  return D6_FMA(dz, dz, D6_FMA(dx, dx, dy * dy));
+}
+
+/* core/pcdet/ops/pointnet2/pointnet2_batch/src/cuda_utils.h:10-14 */
+ORACLE_API int det6d_oracle_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  return t;
+}
+
+/* sampling_gpu.cu:94-99 (__update) + :159-216 (the halving tree over block_size slots). */
+static void tree_reduce(float *dists, int *dists_i, int block_size) {
+  for (int s = block_size / 2; s >= 1; s >>= 1) {
+    for (int tid = 0; tid < s; ++tid) {
+      const float v1 = dists[tid], v2 = dists[tid + s];
+      const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+      dists[tid] = d6_fmaxf(v1, v2);
+      dists_i[tid] = v2 > v1 ? i2 : i1;
+    }
+  }
+}
+
+/* sampling_gpu.cu:101-222 farthest_point_sampling_kernel<block_size>, one block per scene. */
+ORACLE_API int det6d_oracle_fps(int b, int n, int m, const float *xyz, float *temp, int *idx) {
+  if (b < 0 || n <= 0 || m < 0) return -1;
+  if (m == 0) return 0;
+  const int S = det6d_oracle_opt_n_threads(n);
+  float *dists = (float *)malloc(sizeof(float) * S);
+  int *dists_i = (int *)malloc(sizeof(int) * S);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *ds = xyz + (size_t)bi * n * 3;
+    float *tp = temp + (size_t)bi * n;
+    int *out = idx + (size_t)bi * m;
+    int old = 0;
+    out[0] = old;
+    for (int j = 1; j < m; ++j) {
+      const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1], z1 = ds[old * 3 + 2];
+      for (int tid = 0; tid < S; ++tid) {
+        int besti = 0;
+        float best = -1.0f;
+        for (int k = tid; k < n; k += S) {
+          const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
+          const float d = sqdist(x2 - x1, y2 - y1, z2 - z1);
+          const float d2 = d6_fminf(d, tp[k]);
+          tp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      tree_reduce(dists, dists_i, S);
+      old = dists_i[0];
+      out[j] = old;
+    }
+  }
+  free(dists);
+  free(dists_i);
+  return 0;
+}
+
+/* sampling_gpu.cu:419-540 furthest_point_sampling_weights_kernel<block_size>. */
+ORACLE_API int det6d_oracle_fps_weights(int b, int n, int m, const float *xyz, const float *weights,
+                                        float *temp, int *idx) {
+  if (b < 0 || n <= 0 || m < 0) return -1;
+  if (m == 0) return 0;
+  const int S = det6d_oracle_opt_n_threads(n);
+  float *dists = (float *)malloc(sizeof(float) * S);
+  int *dists_i = (int *)malloc(sizeof(int) * S);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *ds = xyz + (size_t)bi * n * 3;
+    const float *w = weights + (size_t)bi * n;
+    float *tp = temp + (size_t)bi * n;
+    int *out = idx + (size_t)bi * m;
+    int old = 0;
+    for (int j = 0; j < m; ++j) {
+      const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1], z1 = ds[old * 3 + 2];
+      for (int tid = 0; tid < S; ++tid) {
+        int besti = 0;
+        float best = -1.0f;
+        for (int k = tid; k < n; k += S) {
+          if (j == 0) {
+            const float d = w[k];
+            besti = d > best ? k : besti;
+            best = d > best ? d : best;
+          } else {
+            const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
+            float d = sqdist(x2 - x1, y2 - y1, z2 - z1);
+            d = d6_fminf(d, tp[k]);
+            tp[k] = d;
+            /* `d * max(weights[k], 1e-12)`: 1e-12 is a double literal, product formed in
+             * double and rounded once to float (sampling_gpu.cu:466). */
+            const double wk = fmax((double)w[k], 1e-12);
+            const float d2 = (float)((double)d * wk);
+            besti = d2 > best ? k : besti;
+            best = d2 > best ? d2 : best;
+          }
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      tree_reduce(dists, dists_i, S);
+      old = dists_i[0];
+      out[j] = old;
+    }
+  }
+  free(dists);
+  free(dists_i);
+  return 0;
+}
+
+/* sampling_gpu.cu:16-32 gather_points_kernel_fast */
+ORACLE_API int det6d_oracle_gather_points(int b, int c, int n, int npoints, const float *points,
+                                          const int *idx, float *out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int j = 0; j < npoints; ++j)
+        out[((size_t)bi * c + ci) * npoints + j] =
+            points[((size_t)bi * c + ci) * n + idx[(size_t)bi * npoints + j]];
+  return 0;
+}
+
+/* sampling_gpu.cu:54-71 gather_points_grad_kernel_fast (sequential sum order on the CPU) */
+ORACLE_API int det6d_oracle_gather_points_grad(int b, int c, int n, int npoints,
+                                               const float *grad_out, const int *idx,
+                                               float *grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int j = 0; j < npoints; ++j)
+        grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * npoints + j]] +=
+            grad_out[((size_t)bi * c + ci) * npoints + j];
+  return 0;
+}
+
+/* ball_query_gpu.cu:15-51 ball_query_kernel_fast */
+ORACLE_API int det6d_oracle_ball_query(int b, int n, int m, float radius, int nsample,
+                                       const float *new_xyz, const float *xyz, int *idx) {
+  const float radius2 = radius * radius;
+  for (int bi = 0; bi < b; ++bi)
+    for (int pi = 0; pi < m; ++pi) {
+      const float *q = new_xyz + ((size_t)bi * m + pi) * 3;
+      const float *p = xyz + (size_t)bi * n * 3;
+      int *o = idx + ((size_t)bi * m + pi) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        const float d2 = sqdist(q[0] - p[k * 3 + 0], q[1] - p[k * 3 + 1], q[2] - p[k * 3 + 2]);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = k;
+          o[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+  return 0;
+}
+
+/* ball_query_gpu.cu:93-130 ball_query_cnt_kernel_fast; :53-91 ball_query_dilated_kernel_fast.
+ * radius_in < 0 selects the plain ball (no inner test). */
+static int ball_query_shell(int b, int n, int m, int dilated, float radius_in, float radius_out,
+                            int nsample, const float *new_xyz, const float *xyz, int *idx_cnt,
+                            int *idx) {
+  const float rin2 = radius_in * radius_in;
+  const float rout2 = radius_out * radius_out;
+  for (int bi = 0; bi < b; ++bi)
+    for (int pi = 0; pi < m; ++pi) {
+      const float *q = new_xyz + ((size_t)bi * m + pi) * 3;
+      const float *p = xyz + (size_t)bi * n * 3;
+      int *o = idx + ((size_t)bi * m + pi) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        const float d2 = sqdist(q[0] - p[k * 3 + 0], q[1] - p[k * 3 + 1], q[2] - p[k * 3 + 2]);
+        const int hit = dilated ? (d2 >= rin2 && d2 < rout2) : (d2 < rout2);
+        if (hit) {
+          o[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+      idx_cnt[(size_t)bi * m + pi] = cnt;
+      for (int l = 0; cnt < nsample; ++l, ++cnt) o[cnt] = o[l];
+    }
+  return 0;
+}
+ORACLE_API int det6d_oracle_ball_query_cnt(int b, int n, int m, float radius, int nsample,
+                                           const float *new_xyz, const float *xyz, int *idx_cnt,
+                                           int *idx) {
+  return ball_query_shell(b, n, m, 0, 0.0f, radius, nsample, new_xyz, xyz, idx_cnt, idx);
+}
+ORACLE_API int det6d_oracle_ball_query_dilated(int b, int n, int m, float radius_in,
+                                               float radius_out, int nsample, const float *new_xyz,
+                                               const float *xyz, int *idx_cnt, int *idx) {
+  return ball_query_shell(b, n, m, 1, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx);
+}
+
+/* group_points_gpu.cu:53-72 group_points_kernel_fast */
+ORACLE_API int det6d_oracle_group_points(int b, int c, int n, int npoints, int nsample,
+                                         const float *points, const int *idx, float *out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int pi = 0; pi < npoints; ++pi)
+        for (int s = 0; s < nsample; ++s)
+          out[(((size_t)bi * c + ci) * npoints + pi) * nsample + s] =
+              points[((size_t)bi * c + ci) * n + idx[((size_t)bi * npoints + pi) * nsample + s]];
+  return 0;
+}
+
+/* group_points_gpu.cu:14-31 group_points_grad_kernel_fast */
+ORACLE_API int det6d_oracle_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                              const float *grad_out, const int *idx,
+                                              float *grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int pi = 0; pi < npoints; ++pi)
+        for (int s = 0; s < nsample; ++s)
+          grad_points[((size_t)bi * c + ci) * n + idx[((size_t)bi * npoints + pi) * nsample + s]] +=
+              grad_out[(((size_t)bi * c + ci) * npoints + pi) * nsample + s];
+  return 0;
+}
+
+/* interpolate_gpu.cu:16-59 three_nn_kernel_fast */
+ORACLE_API int det6d_oracle_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                                     float *dist2, int *idx) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int pi = 0; pi < n; ++pi) {
+      const float *u = unknown + ((size_t)bi * n + pi) * 3;
+      const float *kn = known + (size_t)bi * m * 3;
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float d = sqdist(u[0] - kn[k * 3 + 0], u[1] - kn[k * 3 + 1], u[2] - kn[k * 3 + 2]);
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float *od = dist2 + ((size_t)bi * n + pi) * 3;
+      int *oi = idx + ((size_t)bi * n + pi) * 3;
+      od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+      oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+  return 0;
+}
+
+/* interpolate_gpu.cu:84-104 three_interpolate_kernel_fast;
+ * `w0*p0 + w1*p1 + w2*p2` contracted as fma(w2,p2, fma(w0,p0, w1*p1)). */
+ORACLE_API int det6d_oracle_three_interpolate(int b, int c, int m, int n, const float *points,
+                                              const int *idx, const float *weight, float *out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      const float *p = points + ((size_t)bi * c + ci) * m;
+      for (int pi = 0; pi < n; ++pi) {
+        const float *w = weight + ((size_t)bi * n + pi) * 3;
+        const int *id = idx + ((size_t)bi * n + pi) * 3;
+        out[((size_t)bi * c + ci) * n + pi] =
+            D6_FMA(w[2], p[id[2]], D6_FMA(w[0], p[id[0]], w[1] * p[id[1]]));
+      }
+    }
+  return 0;
+}
+
+/* interpolate_gpu.cu:127-149 three_interpolate_grad_kernel_fast */
+ORACLE_API int det6d_oracle_three_interpolate_grad(int b, int c, int n, int m,
+                                                   const float *grad_out, const int *idx,
+                                                   const float *weight, float *grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      float *gp = grad_points + ((size_t)bi * c + ci) * m;
+      for (int pi = 0; pi < n; ++pi) {
+        const float g = grad_out[((size_t)bi * c + ci) * n + pi];
+        const float *w = weight + ((size_t)bi * n + pi) * 3;
+        const int *id = idx + ((size_t)bi * n + pi) * 3;
+        gp[id[0]] += g * w[0];
+        gp[id[1]] += g * w[1];
+        gp[id[2]] += g * w[2];
+      }
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Rotated BEV overlap. Follows core/pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:59-229
+ * (== iou3d_nms_kernel.cu:35-234 modulo nvcc's FMA contraction), written over plain float
+ * pairs instead of the reference's Point class.
+ * ---------------------------------------------------------------------------------------- */
+#define IOU_EPS 1e-8f
+
+static inline float fmin_ref(float a, float b) { return a > b ? b : a; } /* iou3d_cpu.cpp:30-32 */
+static inline float fmax_ref(float a, float b) { return a > b ? a : b; } /* iou3d_cpu.cpp:34-36 */
+
+/* cross(p1, p2, p0), iou3d_cpu.cpp:63-65 */
+static inline float cross3(const float *p1, const float *p2, const float *p0) {
+  return (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1]);
+}
+
+/* intersection(p1, p0, q1, q0, ans), iou3d_cpu.cpp:87-116 */
+static int seg_intersection(const float *p1, const float *p0, const float *q1, const float *q0,
+                            float *ans) {
+  /* check_rect_cross(p0, p1, q0, q1), iou3d_cpu.cpp:67-73 */
+  const int rect = fmin_ref(p0[0], p1[0]) <= fmax_ref(q0[0], q1[0]) &&
+                   fmin_ref(q0[0], q1[0]) <= fmax_ref(p0[0], p1[0]) &&
+                   fmin_ref(p0[1], p1[1]) <= fmax_ref(q0[1], q1[1]) &&
+                   fmin_ref(q0[1], q1[1]) <= fmax_ref(p0[1], p1[1]);
+  if (!rect) return 0;
+  const float s1 = cross3(q0, p1, p0);
+  const float s2 = cross3(p1, q1, p0);
+  const float s3 = cross3(p0, q1, q0);
+  const float s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  const float s5 = cross3(q1, p1, p0);
+  if (d6_fabsf(s5 - s1) > IOU_EPS) {
+    ans[0] = (s5 * q0[0] - s1 * q1[0]) / (s5 - s1);
+    ans[1] = (s5 * q0[1] - s1 * q1[1]) / (s5 - s1);
+  } else {
+    const float a0 = p0[1] - p1[1], b0 = p1[0] - p0[0], c0 = p0[0] * p1[1] - p1[0] * p0[1];
+    const float a1 = q0[1] - q1[1], b1 = q1[0] - q0[0], c1 = q0[0] * q1[1] - q1[0] * q0[1];
+    const float D = a0 * b1 - a1 * b0;
+    ans[0] = (b0 * c1 - b1 * c0) / D;
+    ans[1] = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+/* check_in_box2d, iou3d_cpu.cpp:75-85; cos(-t) = cos t, sin(-t) = -sin t exactly */
+static int point_in_box2d(const float *box, float bcos, float bsin, const float *p) {
+  const float MARGIN = 1e-2f;
+  const float angle_cos = bcos, angle_sin = -bsin;
+  const float rot_x = (p[0] - box[0]) * angle_cos + (p[1] - box[1]) * (-angle_sin);
+  const float rot_y = (p[0] - box[0]) * angle_sin + (p[1] - box[1]) * angle_cos;
+  return d6_fabsf(rot_x) < box[3] / 2 + MARGIN && d6_fabsf(rot_y) < box[4] / 2 + MARGIN;
+}
+
+/* box_overlap, iou3d_cpu.cpp:128-220 */
+static float box_overlap(const float *box_a, const float *box_b) {
+  const float a_angle = box_a[6], b_angle = box_b[6];
+  const float a_dx_half = box_a[3] / 2, b_dx_half = box_b[3] / 2;
+  const float a_dy_half = box_a[4] / 2, b_dy_half = box_b[4] / 2;
+  const float a_x1 = box_a[0] - a_dx_half, a_y1 = box_a[1] - a_dy_half;
+  const float a_x2 = box_a[0] + a_dx_half, a_y2 = box_a[1] + a_dy_half;
+  const float b_x1 = box_b[0] - b_dx_half, b_y1 = box_b[1] - b_dy_half;
+  const float b_x2 = box_b[0] + b_dx_half, b_y2 = box_b[1] + b_dy_half;
+
+  float ca[5][2] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
+  float cb[5][2] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
+
+  float a_sin, a_cos, b_sin, b_cos;
+  d6_sincosf(a_angle, &a_sin, &a_cos);
+  d6_sincosf(b_angle, &b_sin, &b_cos);
+
+  for (int k = 0; k < 4; ++k) { /* rotate_around_center, iou3d_cpu.cpp:118-122 */
+    float nx = (ca[k][0] - box_a[0]) * a_cos + (ca[k][1] - box_a[1]) * (-a_sin) + box_a[0];
+    float ny = (ca[k][0] - box_a[0]) * a_sin + (ca[k][1] - box_a[1]) * a_cos + box_a[1];
+    ca[k][0] = nx; ca[k][1] = ny;
+    nx = (cb[k][0] - box_b[0]) * b_cos + (cb[k][1] - box_b[1]) * (-b_sin) + box_b[0];
+    ny = (cb[k][0] - box_b[0]) * b_sin + (cb[k][1] - box_b[1]) * b_cos + box_b[1];
+    cb[k][0] = nx; cb[k][1] = ny;
+  }
+  ca[4][0] = ca[0][0]; ca[4][1] = ca[0][1];
+  cb[4][0] = cb[0][0]; cb[4][1] = cb[0][1];
+
+  float cp[16][2];
+  float cx = 0.f, cy = 0.f;
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], cp[cnt])) {
+        cx = cx + cp[cnt][0];
+        cy = cy + cp[cnt][1];
+        ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (point_in_box2d(box_a, a_cos, a_sin, cb[k])) {
+      cx = cx + cb[k][0]; cy = cy + cb[k][1];
+      cp[cnt][0] = cb[k][0]; cp[cnt][1] = cb[k][1];
+      ++cnt;
+    }
+    if (point_in_box2d(box_b, b_cos, b_sin, ca[k])) {
+      cx = cx + ca[k][0]; cy = cy + ca[k][1];
+      cp[cnt][0] = ca[k][0]; cp[cnt][1] = ca[k][1];
+      ++cnt;
+    }
+  }
+  cx /= cnt; /* cnt == 0 -> NaN, harmless: the loops below do not run */
+  cy /= cnt;
+
+  /* bubble sort by polar angle about the centroid, iou3d_cpu.cpp:124-126,198-208 */
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i) {
+      const float ta = d6_atan2f(cp[i][1] - cy, cp[i][0] - cx);
+      const float tb = d6_atan2f(cp[i + 1][1] - cy, cp[i + 1][0] - cx);
+      if (ta > tb) {
+        const float tx = cp[i][0], ty = cp[i][1];
+        cp[i][0] = cp[i + 1][0]; cp[i][1] = cp[i + 1][1];
+        cp[i + 1][0] = tx; cp[i + 1][1] = ty;
+      }
+    }
+
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    const float ax = cp[k][0] - cp[0][0], ay = cp[k][1] - cp[0][1];
+    const float bx = cp[k + 1][0] - cp[0][0], by = cp[k + 1][1] - cp[0][1];
+    area += ax * by - ay * bx;
+  }
+  return (float)(fabs((double)area) / 2.0);
+}
+
+/* iou_bev, iou3d_cpu.cpp:222-229 */
+static float iou_bev(const float *box_a, const float *box_b) {
+  const float sa = box_a[3] * box_a[4];
+  const float sb = box_b[3] * box_b[4];
+  const float s_overlap = box_overlap(box_a, box_b);
+  return s_overlap / d6_fmaxf(sa + sb - s_overlap, IOU_EPS);
+}
+
+/* iou_normal, iou3d_nms_kernel.cu:314-325 */
+static float iou_normal(const float *a, const float *b) {
+  const float left = d6_fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2);
+  const float right = d6_fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  const float top = d6_fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2);
+  const float bottom = d6_fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  const float width = d6_fmaxf(right - left, 0.f), height = d6_fmaxf(bottom - top, 0.f);
+  const float interS = width * height;
+  const float Sa = a[3] * a[4];
+  const float Sb = b[3] * b[4];
+  return interS / d6_fmaxf(Sa + Sb - interS, IOU_EPS);
+}
+
+/* boxes_overlap_kernel / boxes_iou_bev_kernel, iou3d_nms_kernel.cu:236-265;
+ * boxes_iou_bev_cpu, iou3d_cpu.cpp:232-252 */
+ORACLE_API int det6d_oracle_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b,
+                                              const float *boxes_b, float *ans) {
+  for (int i = 0; i < num_a; ++i)
+    for (int j = 0; j < num_b; ++j)
+      ans[(size_t)i * num_b + j] = box_overlap(boxes_a + i * 7, boxes_b + j * 7);
+  return 0;
+}
+ORACLE_API int det6d_oracle_boxes_iou_bev(int num_a, const float *boxes_a, int num_b,
+                                          const float *boxes_b, float *ans) {
+  for (int i = 0; i < num_a; ++i)
+    for (int j = 0; j < num_b; ++j)
+      ans[(size_t)i * num_b + j] = iou_bev(boxes_a + i * 7, boxes_b + j * 7);
+  return 0;
+}
+
+ORACLE_API int64_t det6d_oracle_nms_mask_words(int boxes_num) {
+  return (int64_t)boxes_num * ((boxes_num + 63) / 64);
+}
+
+/* nms_kernel / nms_normal_kernel tiles, iou3d_nms_kernel.cu:267-311,328-372 */
+ORACLE_API int det6d_oracle_nms_mask(int boxes_num, const float *boxes, float thresh, int normal,
+                                     uint64_t *mask) {
+  const int col_blocks = (boxes_num + 63) / 64;
+  for (int i = 0; i < boxes_num; ++i) {
+    const int row_start = i / 64, t = i % 64;
+    for (int col_start = 0; col_start < col_blocks; ++col_start) {
+      int col_size = boxes_num - col_start * 64;
+      if (col_size > 64) col_size = 64;
+      uint64_t bits = 0;
+      const int start = (row_start == col_start) ? t + 1 : 0;
+      for (int c = start; c < col_size; ++c) {
+        const float *bj = boxes + (size_t)(col_start * 64 + c) * 7;
+        const float v = normal ? iou_normal(boxes + (size_t)i * 7, bj) : iou_bev(boxes + (size_t)i * 7, bj);
+        if (v > thresh) bits |= 1ULL << c;
+      }
+      mask[(size_t)i * col_blocks + col_start] = bits;
+    }
+  }
+  return 0;
+}
+
+/* host greedy scan of nms_gpu, iou3d_nms.cpp:116-132 */
+static int nms_greedy(int boxes_num, const uint64_t *mask, int64_t *keep) {
+  const int col_blocks = (boxes_num + 63) / 64;
+  uint64_t *remv = (uint64_t *)calloc(col_blocks > 0 ? col_blocks : 1, sizeof(uint64_t));
+  int num_to_keep = 0;
+  for (int i = 0; i < boxes_num; ++i) {
+    const int nblock = i / 64, inblock = i % 64;
+    if (!(remv[nblock] & (1ULL << inblock))) {
+      keep[num_to_keep++] = i;
+      const uint64_t *p = mask + (size_t)i * col_blocks;
+      for (int j = nblock; j < col_blocks; ++j) remv[j] |= p[j];
+    }
+  }
+  free(remv);
+  return num_to_keep;
+}
+
+ORACLE_API int det6d_oracle_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask,
+                                int64_t *keep, int *num_keep) {
+  det6d_oracle_nms_mask(boxes_num, boxes, thresh, 0, mask);
+  *num_keep = nms_greedy(boxes_num, mask, keep);
+  return 0;
+}
+ORACLE_API int det6d_oracle_nms_normal(int boxes_num, const float *boxes, float thresh,
+                                       uint64_t *mask, int64_t *keep, int *num_keep) {
+  det6d_oracle_nms_mask(boxes_num, boxes, thresh, 1, mask);
+  *num_keep = nms_greedy(boxes_num, mask, keep);
+  return 0;
+}
+
+/* greedy scan over a given IoU matrix (used to derive keep lists from oracle/_ref's matrices) */
+ORACLE_API int det6d_oracle_nms_from_iou(int boxes_num, const float *iou, float thresh,
+                                         int64_t *keep) {
+  const int col_blocks = (boxes_num + 63) / 64;
+  uint64_t *mask = (uint64_t *)calloc((size_t)boxes_num * (col_blocks > 0 ? col_blocks : 1) + 1,
+                                      sizeof(uint64_t));
+  for (int i = 0; i < boxes_num; ++i)
+    for (int j = i + 1; j < boxes_num; ++j)
+      if (iou[(size_t)i * boxes_num + j] > thresh) mask[(size_t)i * col_blocks + j / 64] |= 1ULL << (j % 64);
+  const int n = nms_greedy(boxes_num, mask, keep);
+  free(mask);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Engine-level ops (restating the Python hot loop)
+ * ---------------------------------------------------------------------------------------- */
+
+/* PointNet2FSMSG.break_up_pc + view, core/pcdet/models/backbones_3d/pointnet2_backbone.py:193-224 */
+ORACLE_API int det6d_oracle_pack_points(int total, int cin, const float *points, int ld,
+                                        float *rows) {
+  for (int i = 0; i < total; ++i) {
+    const float *src = points + (size_t)i * (1 + 3 + cin);
+    float *dst = rows + (size_t)i * ld;
+    for (int c = 0; c < 3 + cin; ++c) dst[c] = src[1 + c];
+    for (int c = 3 + cin; c < ld; ++c) dst[c] = 0.f;
+  }
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol,
+                                        const float *rows_in, const int *idx, float *rows_out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      const float *src = rows_in + ((size_t)bi * n + idx[(size_t)bi * m + j]) * ld_in;
+      float *dst = rows_out + ((size_t)bi * m + j) * ld_out;
+      for (int c = 0; c < ncol; ++c) dst[c] = src[c];
+    }
+  return 0;
+}
+
+typedef struct det6d_linear_args {
+  int mode, rows, k, ncols;
+  const float *a; int lda;
+  const float *w; int ldw;
+  const float *shift;
+  int act;
+  float *y; int ldy; int col0;
+  int n, m, ns;
+  const int *idx;
+  const float *ctr; int ldctr;
+  int pool;
+  const int *cnt;
+} det6d_linear_args;
+
+/* Conv(1x1, bias=False) -> BatchNorm(eval) -> ReLU with BN folded into W/shift
+ * (pointnet2_modules.py:561-568), grouping (pointnet2_utils.py:449-455), mask + max-pool
+ * (pointnet2_modules.py:465-472).  Every output is ONE ascending-k fmaf chain starting at 0,
+ * then `+ shift`, then ReLU — the exact arithmetic of v_mfma_f32_32x32x2_f32. */
+ORACLE_API int det6d_oracle_linear(const det6d_linear_args *g) {
+  const int K = g->k, N = g->ncols;
+  if (g->pool && (g->rows % g->pool)) return -1;
+#pragma omp parallel
+  {
+    float *arow = (float *)malloc(sizeof(float) * (K > 0 ? K : 1));
+    float *acc = (float *)malloc(sizeof(float) * N);
+    float *best = (float *)malloc(sizeof(float) * N);
+    const int ngroups = g->pool ? g->rows / g->pool : g->rows;
+    const int per = g->pool ? g->pool : 1;
+#pragma omp for schedule(static)
+    for (int gi = 0; gi < ngroups; ++gi) {
+      for (int s = 0; s < per; ++s) {
+        const int r = gi * per + s;
+        if (g->mode == 1) {
+          const int cj = r / g->ns;          /* flat centre index b*m + j */
+          const int bi = cj / g->m;
+          const int p = g->idx[r];
+          const float *src = g->a + ((size_t)bi * g->n + p) * g->lda;
+          const float *c = g->ctr + (size_t)cj * g->ldctr;
+          for (int k = 0; k < K; ++k) arow[k] = k < 3 ? src[k] - c[k] : src[k];
+        } else {
+          const float *src = g->a + (size_t)r * g->lda;
+          for (int k = 0; k < K; ++k) arow[k] = src[k];
+        }
+        for (int c = 0; c < N; ++c) acc[c] = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float av = arow[k];
+          const float *wr = g->w + (size_t)k * g->ldw;
+          for (int c = 0; c < N; ++c) acc[c] = D6_FMA(av, wr[c], acc[c]);
+        }
+        for (int c = 0; c < N; ++c) {
+          float v = g->shift ? acc[c] + g->shift[c] : acc[c];
+          if (g->act == 1) v = v > 0.f ? v : 0.f;
+          acc[c] = v;
+        }
+        if (g->pool) {
+          if (s == 0) for (int c = 0; c < N; ++c) best[c] = acc[c];
+          else for (int c = 0; c < N; ++c) best[c] = acc[c] > best[c] ? acc[c] : best[c];
+        } else {
+          float *dst = g->y + (size_t)r * g->ldy + g->col0;
+          for (int c = 0; c < N; ++c) dst[c] = acc[c];
+        }
+      }
+      if (g->pool) {
+        const int live = g->cnt ? g->cnt[gi] > 0 : 1;
+        float *dst = g->y + (size_t)gi * g->ldy + g->col0;
+        for (int c = 0; c < N; ++c) dst[c] = live ? best[c] : 0.f;
+      }
+    }
+    free(arow); free(acc); free(best);
+  }
+  return 0;
+}
+
+/* pointnet2_modules.py:415-419 */
+ORACLE_API int det6d_oracle_sigmoid_pow(int count, const float *scores, float gamma, float *weights) {
+  for (int i = 0; i < count; ++i) weights[i] = d6_sigmoid_powf(scores[i], gamma);
+  return 0;
+}
+
+/* point_head_box6d_vote.py:816-821: torch.max(off, -R) then torch.min(., R), then add */
+ORACLE_API int det6d_oracle_vote_points(int rows, const float *off, int ldo, const float *cand,
+                                        int ldc, float rx, float ry, float rz, float *vote, int ldv,
+                                        float *off_out) {
+  const float R[3] = {rx, ry, rz};
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float o = off[(size_t)r * ldo + c];
+      o = o > -R[c] ? o : -R[c];
+      o = o < R[c] ? o : R[c];
+      if (off_out) off_out[(size_t)r * 3 + c] = o;
+      vote[(size_t)r * ldv + c] = cand[(size_t)r * ldc + c] + o;
+    }
+  return 0;
+}
+
+/* PointBinResidual6DCoder.decode_torch (use_mean_size=False),
+ * core/pcdet/utils/box_coder_utils.py:589-603 (yaw bins), :622-640 (pitch), :642-680 (kernel) */
+ORACLE_API int det6d_oracle_decode_boxes(int rows, int nbin, int ground_aware, int minus,
+                                         float threshold_rad, float factor_rad, const float *code,
+                                         int ldcode, const float *pts, int ldp, float *boxes) {
+  const float per_bin = (float)(3.14159265358979323846 * 2.0 / (double)nbin);
+  for (int r = 0; r < rows; ++r) {
+    const float *c = code + (size_t)r * ldcode;
+    const float *p = pts + (size_t)r * ldp;
+    float *o = boxes + (size_t)r * 9;
+    o[0] = c[0] + p[0];
+    o[1] = c[1] + p[1];
+    o[2] = c[2] + p[2];
+    o[3] = d6_expf(c[3]);
+    o[4] = d6_expf(c[4]);
+    o[5] = d6_expf(c[5]);
+    const float *bin = c + 6, *res = c + 6 + nbin, *gr = c + 6 + 2 * nbin;
+    int am = 0;
+    for (int i = 1; i < nbin; ++i)
+      if (bin[i] > bin[am]) am = i;
+    o[6] = ((float)am + res[am]) * per_bin;
+    if (ground_aware) {
+      const int no_pitch = d6_sigmoidf(gr[0]) < 0.5f;
+      float pitch = minus ? gr[1] * factor_rad : (-threshold_rad) - gr[1] * factor_rad;
+      if (no_pitch) pitch = 0.f;
+      o[7] = pitch;
+    } else {
+      o[7] = gr[0];
+    }
+    o[8] = 0.f;
+  }
+  return 0;
+}
+
+/* Detector3DTemplate.post_processing (eval, class-agnostic NMS),
+ * core/pcdet/models/detectors/detector3d_template.py:178-284,
+ * core/pcdet/models/model_utils/model_nms_utils.py:6-25,
+ * core/pcdet/ops/iou3d_nms/iou3d_nms_utils.py:84-99 */
+ORACLE_API int det6d_oracle_postprocess(int b, int p, int ncls, const float *cls,
+                                        const float *boxes, float score_thr, int pre_max,
+                                        int post_max, float nms_thr, float *out_boxes,
+                                        float *out_scores, int *out_labels, int *out_index,
+                                        int *out_count) {
+  float *score = (float *)malloc(sizeof(float) * p);
+  int *label = (int *)malloc(sizeof(int) * p);
+  int *order = (int *)malloc(sizeof(int) * p);
+  float *sorted = (float *)malloc(sizeof(float) * 7 * p);
+  uint64_t *mask = (uint64_t *)malloc(sizeof(uint64_t) * (det6d_oracle_nms_mask_words(p) + 1));
+  int64_t *keep = (int64_t *)malloc(sizeof(int64_t) * p);
+  for (int bi = 0; bi < b; ++bi) {
+    int cand = 0;
+    for (int i = 0; i < p; ++i) {
+      const float *lg = cls + ((size_t)bi * p + i) * ncls;
+      float best = d6_sigmoidf(lg[0]);
+      int bl = 0;
+      for (int c = 1; c < ncls; ++c) {
+        const float s = d6_sigmoidf(lg[c]);
+        if (s > best) { best = s; bl = c; }
+      }
+      score[i] = best;
+      label[i] = bl + 1;
+      if (best >= score_thr) order[cand++] = i;
+    }
+    /* stable descending insertion sort == topk(sorted) + sort(descending) with ties by index */
+    for (int i = 1; i < cand; ++i) {
+      const int v = order[i];
+      int j = i - 1;
+      while (j >= 0 && score[order[j]] < score[v]) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = v;
+    }
+    if (cand > pre_max) cand = pre_max;
+    for (int i = 0; i < cand; ++i)
+      for (int c = 0; c < 7; ++c) sorted[i * 7 + c] = boxes[((size_t)bi * p + order[i]) * 9 + c];
+    int nkeep = 0;
+    if (cand > 0) det6d_oracle_nms(cand, sorted, nms_thr, mask, keep, &nkeep);
+    if (nkeep > post_max) nkeep = post_max;
+    out_count[bi] = nkeep;
+    for (int i = 0; i < post_max; ++i) {
+      float *ob = out_boxes + ((size_t)bi * post_max + i) * 9;
+      if (i < nkeep) {
+        const int src = order[keep[i]];
+        for (int c = 0; c < 9; ++c) ob[c] = boxes[((size_t)bi * p + src) * 9 + c];
+        out_scores[(size_t)bi * post_max + i] = score[src];
+        out_labels[(size_t)bi * post_max + i] = label[src];
+        out_index[(size_t)bi * post_max + i] = src;
+      } else {
+        for (int c = 0; c < 9; ++c) ob[c] = 0.f;
+        out_scores[(size_t)bi * post_max + i] = 0.f;
+        out_labels[(size_t)bi * post_max + i] = 0;
+        out_index[(size_t)bi * post_max + i] = -1;
+      }
+    }
+  }
+  free(score); free(label); free(order); free(sorted); free(mask); free(keep);
+  return 0;
+}
+
+/* math probes for tests/test_math.py */
+ORACLE_API void det6d_oracle_math(int fn, int count, const float *x, const float *y, float *out) {
+  for (int i = 0; i < count; ++i) {
+    switch (fn) {
+      case 0: out[i] = d6_expf(x[i]); break;
+      case 1: out[i] = d6_logf(x[i]); break;
+      case 2: out[i] = d6_sinf(x[i]); break;
+      case 3: out[i] = d6_cosf(x[i]); break;
+      case 4: out[i] = d6_atan2f(y[i], x[i]); break;
+      case 5: out[i] = d6_sigmoidf(x[i]); break;
+      default: out[i] = 0.f;
+    }
+  }
+}

@@ -1,0 +1,341 @@
+"""numpy front-end of libdet6d_oracle.so (see oracle/det6d_oracle.c).  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdet6d_oracle.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int)
+_lp = ctypes.POINTER(ctypes.c_int64)
+_up = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds). Building the checker is not using it."""
+    src = os.path.join(_HERE, "det6d_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "det6d_math.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "libdet6d_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+def opt_n_threads(n):
+    return int(lib().det6d_oracle_opt_n_threads(_c_int(n)))
+
+
+def fps(xyz, m, temp=None):
+    xyz = _f(xyz)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, np.float32) if temp is None else temp
+    idx = np.zeros((b, m), np.int32)
+    rc = lib().det6d_oracle_fps(b, n, m, _pf(xyz), _pf(temp), _pi(idx))
+    assert rc == 0
+    return idx
+
+
+def fps_weights(xyz, weights, m, temp=None):
+    xyz, weights = _f(xyz), _f(weights)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, np.float32) if temp is None else temp
+    idx = np.zeros((b, m), np.int32)
+    rc = lib().det6d_oracle_fps_weights(b, n, m, _pf(xyz), _pf(weights), _pf(temp), _pi(idx))
+    assert rc == 0
+    return idx
+
+
+def gather_points(points, idx):
+    points, idx = _f(points), _i(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.empty((b, c, m), np.float32)
+    lib().det6d_oracle_gather_points(b, c, n, m, _pf(points), _pi(idx), _pf(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    grad_out, idx = _f(grad_out), _i(idx)
+    b, c, m = grad_out.shape
+    gp = np.zeros((b, c, n), np.float32)
+    lib().det6d_oracle_gather_points_grad(b, c, n, m, _pf(grad_out), _pi(idx), _pf(gp))
+    return gp
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f(xyz), _f(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    lib().det6d_oracle_ball_query(b, n, m, _c_float(radius), nsample, _pf(new_xyz), _pf(xyz), _pi(idx))
+    return idx
+
+
+def ball_query_cnt(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f(xyz), _f(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    cnt = np.zeros((b, m), np.int32)
+    lib().det6d_oracle_ball_query_cnt(b, n, m, _c_float(radius), nsample, _pf(new_xyz), _pf(xyz),
+                                      _pi(cnt), _pi(idx))
+    return cnt, idx
+
+
+def ball_query_dilated(radius_in, radius_out, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f(xyz), _f(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    cnt = np.zeros((b, m), np.int32)
+    lib().det6d_oracle_ball_query_dilated(b, n, m, _c_float(radius_in), _c_float(radius_out), nsample,
+                                          _pf(new_xyz), _pf(xyz), _pi(cnt), _pi(idx))
+    return cnt, idx
+
+
+def group_points(points, idx):
+    points, idx = _f(points), _i(idx)
+    b, c, n = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, c, m, ns), np.float32)
+    lib().det6d_oracle_group_points(b, c, n, m, ns, _pf(points), _pi(idx), _pf(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    grad_out, idx = _f(grad_out), _i(idx)
+    b, c, m, ns = grad_out.shape
+    gp = np.zeros((b, c, n), np.float32)
+    lib().det6d_oracle_group_points_grad(b, c, n, m, ns, _pf(grad_out), _pi(idx), _pf(gp))
+    return gp
+
+
+def three_nn(unknown, known):
+    unknown, known = _f(unknown), _f(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    lib().det6d_oracle_three_nn(b, n, m, _pf(unknown), _pf(known), _pf(d2), _pi(idx))
+    return d2, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, c, n), np.float32)
+    lib().det6d_oracle_three_interpolate(b, c, m, n, _pf(points), _pi(idx), _pf(weight), _pf(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, idx, weight = _f(grad_out), _i(idx), _f(weight)
+    b, c, n = grad_out.shape
+    gp = np.zeros((b, c, m), np.float32)
+    lib().det6d_oracle_three_interpolate_grad(b, c, n, m, _pf(grad_out), _pi(idx), _pf(weight), _pf(gp))
+    return gp
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    a, b = _f(boxes_a), _f(boxes_b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    lib().det6d_oracle_boxes_overlap_bev(a.shape[0], _pf(a), b.shape[0], _pf(b), _pf(out))
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    a, b = _f(boxes_a), _f(boxes_b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    lib().det6d_oracle_boxes_iou_bev(a.shape[0], _pf(a), b.shape[0], _pf(b), _pf(out))
+    return out
+
+
+def nms_mask(boxes, thresh, normal=False):
+    boxes = _f(boxes)
+    k = boxes.shape[0]
+    cb = (k + 63) // 64
+    mask = np.zeros((k, max(cb, 1)), np.uint64)
+    lib().det6d_oracle_nms_mask(k, _pf(boxes), _c_float(thresh), int(normal), mask.ctypes.data_as(_up))
+    return mask[:, :cb]
+
+
+def nms(boxes, thresh, normal=False):
+    """boxes (K,7) already sorted by descending score -> keep indices (int64)."""
+    boxes = _f(boxes)
+    k = boxes.shape[0]
+    cb = (k + 63) // 64
+    mask = np.zeros(k * cb + 1, np.uint64)
+    keep = np.zeros(max(k, 1), np.int64)
+    num = _c_int(0)
+    fn = lib().det6d_oracle_nms_normal if normal else lib().det6d_oracle_nms
+    fn(k, _pf(boxes), _c_float(thresh), mask.ctypes.data_as(_up), keep.ctypes.data_as(_lp), ctypes.byref(num))
+    return keep[:num.value].copy()
+
+
+def nms_from_iou(iou, thresh):
+    iou = _f(iou)
+    k = iou.shape[0]
+    keep = np.zeros(max(k, 1), np.int64)
+    n = lib().det6d_oracle_nms_from_iou(k, _pf(iou), _c_float(thresh), keep.ctypes.data_as(_lp))
+    return keep[:n].copy()
+
+
+class _LinearArgs(ctypes.Structure):
+    _fields_ = [("mode", _c_int), ("rows", _c_int), ("k", _c_int), ("ncols", _c_int),
+                ("a", _fp), ("lda", _c_int),
+                ("w", _fp), ("ldw", _c_int),
+                ("shift", _fp),
+                ("act", _c_int),
+                ("y", _fp), ("ldy", _c_int), ("col0", _c_int),
+                ("n", _c_int), ("m", _c_int), ("ns", _c_int),
+                ("idx", _ip),
+                ("ctr", _fp), ("ldctr", _c_int),
+                ("pool", _c_int),
+                ("cnt", _ip)]
+
+
+def linear(a, w, shift=None, act=0, k=None, idx=None, ctr=None, cnt=None, pool=0, out=None, col0=0):
+    """Y = act(A' W + shift).  a: (R,lda) rows, or with idx (B,m,ns): point rows (B,n,lda) gathered
+    and centre-subtracted on the first 3 columns (ctr (B,m,ldctr)).  pool=ns -> masked max-pool."""
+    a, w = _f(a), _f(w)
+    kk = w.shape[0] if k is None else k
+    ncols = w.shape[1]
+    g = _LinearArgs()
+    keep = [a, w]
+    if idx is not None:
+        idx, ctr = _i(idx), _f(ctr)
+        bsz, m, ns = idx.shape
+        g.mode, g.rows = 1, bsz * m * ns
+        g.n, g.m, g.ns = a.shape[1], m, ns
+        g.idx, g.ctr, g.ldctr = _pi(idx), _pf(ctr), ctr.shape[-1]
+        g.lda = a.shape[-1]
+        keep += [idx, ctr]
+    else:
+        a2 = a.reshape(-1, a.shape[-1])
+        g.mode, g.rows, g.lda = 0, a2.shape[0], a2.shape[-1]
+    g.k, g.ncols = kk, ncols
+    g.a, g.w, g.ldw = _pf(a), _pf(w), w.shape[1]
+    if shift is not None:
+        shift = _f(shift)
+        keep.append(shift)
+        g.shift = _pf(shift)
+    g.act = act
+    g.pool = pool
+    nrows_out = g.rows // pool if pool else g.rows
+    if cnt is not None:
+        cnt = _i(cnt)
+        keep.append(cnt)
+        g.cnt = _pi(cnt)
+    if out is None:
+        out = np.zeros((nrows_out, ncols), np.float32)
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    g.y, g.ldy, g.col0 = _pf(out), out.shape[-1], col0
+    rc = lib().det6d_oracle_linear(ctypes.byref(g))
+    assert rc == 0
+    return out
+
+
+def sigmoid_pow(scores, gamma=1.0):
+    s = _f(scores)
+    out = np.empty_like(s)
+    lib().det6d_oracle_sigmoid_pow(s.size, _pf(s), _c_float(gamma), _pf(out))
+    return out
+
+
+def pack_points(points, ld):
+    p = _f(points)
+    total, width = p.shape
+    cin = width - 4
+    rows = np.empty((total, ld), np.float32)
+    lib().det6d_oracle_pack_points(total, cin, _pf(p), ld, _pf(rows))
+    return rows
+
+
+def gather_rows(rows_in, idx, ncol, ld_out=None):
+    rows_in, idx = _f(rows_in), _i(idx)
+    b, n, ld_in = rows_in.shape
+    m = idx.shape[1]
+    ld_out = ncol if ld_out is None else ld_out
+    out = np.zeros((b, m, ld_out), np.float32)
+    lib().det6d_oracle_gather_rows(b, n, m, ld_in, ld_out, ncol, _pf(rows_in), _pi(idx), _pf(out))
+    return out
+
+
+def vote_points(off, cand, rng):
+    off, cand = _f(off), _f(cand)
+    rows = off.shape[0]
+    vote = np.zeros((rows, 3), np.float32)
+    off_out = np.zeros((rows, 3), np.float32)
+    lib().det6d_oracle_vote_points(rows, _pf(off), off.shape[1], _pf(cand), cand.shape[1],
+                                   _c_float(rng[0]), _c_float(rng[1]), _c_float(rng[2]),
+                                   _pf(vote), 3, _pf(off_out))
+    return vote, off_out
+
+
+def decode_boxes(code, pts, nbin=12, ground_aware=True, minus=False, threshold_deg=10.0, factor_deg=45.0):
+    code, pts = _f(code), _f(pts)
+    rows = code.shape[0]
+    boxes = np.empty((rows, 9), np.float32)
+    thr = np.float32(np.deg2rad(threshold_deg))
+    fac = np.float32(np.deg2rad(factor_deg))
+    lib().det6d_oracle_decode_boxes(rows, nbin, int(ground_aware), int(minus), _c_float(thr), _c_float(fac),
+                                    _pf(code), code.shape[1], _pf(pts), pts.shape[1], _pf(boxes))
+    return boxes
+
+
+def postprocess(cls, boxes, b, score_thr, pre_max, post_max, nms_thr):
+    cls, boxes = _f(cls), _f(boxes)
+    p = cls.shape[0] // b
+    ncls = cls.shape[1]
+    ob = np.zeros((b, post_max, 9), np.float32)
+    os_ = np.zeros((b, post_max), np.float32)
+    ol = np.zeros((b, post_max), np.int32)
+    oi = np.zeros((b, post_max), np.int32)
+    oc = np.zeros((b,), np.int32)
+    lib().det6d_oracle_postprocess(b, p, ncls, _pf(cls), _pf(boxes), _c_float(score_thr), pre_max, post_max,
+                                   _c_float(nms_thr), _pf(ob), _pf(os_), _pi(ol), _pi(oi), _pi(oc))
+    return ob, os_, ol, oi, oc
+
+
+def math_fn(name, x, y=None):
+    fn = {"exp": 0, "log": 1, "sin": 2, "cos": 3, "atan2": 4, "sigmoid": 5}[name]
+    x = _f(x)
+    y = _f(y) if y is not None else x
+    out = np.empty_like(x)
+    lib().det6d_oracle_math(fn, x.size, _pf(x), _pf(y), _pf(out))
+    return out
