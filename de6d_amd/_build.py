@@ -1,0 +1,61 @@
+"""Builds de6d_amd/csrc/libdet6d_hip.so (gfx950 only) with hipcc.  Works without a GPU
+(hipcc cross-compiles); the built library is git-ignored but travels with gpurun snapshots."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libdet6d_hip.so")
+SOURCES = ["runtime.hip", "fps.hip", "ball_query.hip", "points.hip", "iou3d_nms.hip", "linear.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"),
+           os.path.join(HERE, "..", "include", "det6d_ops.h"),
+           os.path.join(HERE, "..", "include", "det6d_math.h"),
+           os.path.join(HERE, "..", "include", "det6d_geom.h")]
+# -ffp-contract=off + correctly rounded divide: the arithmetic contract shared with the oracle
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,123 @@
+"""ctypes binding of csrc/libdet6d_hip.so (C ABI: include/det6d_ops.h).
+
+PyTorch is plumbing here: tensors provide device memory (``data_ptr()``) and the current HIP
+stream; nothing below ever computes with torch ops.  There is NO fallback: if the library is
+missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip.so")
+
+c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+
+
+class Det6dError(RuntimeError):
+    pass
+
+
+class LinearArgs(ctypes.Structure):
+    """mirror of det6d_linear_args (include/det6d_ops.h)"""
+    _fields_ = [("mode", c_int), ("rows", c_int), ("k", c_int), ("ncols", c_int),
+                ("a", c_void_p), ("lda", c_int),
+                ("w", c_void_p), ("ldw", c_int),
+                ("shift", c_void_p),
+                ("act", c_int),
+                ("y", c_void_p), ("ldy", c_int), ("col0", c_int),
+                ("n", c_int), ("m", c_int), ("ns", c_int),
+                ("idx", c_void_p),
+                ("ctr", c_void_p), ("ldctr", c_int),
+                ("pool", c_int),
+                ("cnt", c_void_p)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    "det6d_fps": [c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_fps_weights": [c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "det6d_gather_points": [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_gather_points_grad": [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_ball_query": [c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P],
+    "det6d_ball_query_cnt": [c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P],
+    "det6d_ball_query_dilated": [c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P],
+    "det6d_group_points": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_group_points_grad": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_three_nn": [c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "det6d_three_interpolate": [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "det6d_three_interpolate_grad": [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "det6d_boxes_overlap_bev": [c_int, _P, c_int, _P, _P, _P],
+    "det6d_boxes_iou_bev": [c_int, _P, c_int, _P, _P, _P],
+    "det6d_nms": [c_int, _P, c_float, _P, _P, _P, _P],
+    "det6d_nms_normal": [c_int, _P, c_float, _P, _P, _P, _P],
+    "det6d_nms_to_host": [c_int, _P, c_float, _P, c_int, _P],
+    "det6d_pack_points": [c_int, c_int, _P, c_int, _P, _P],
+    "det6d_gather_rows": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "det6d_linear": [ctypes.POINTER(LinearArgs), _P],
+    "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],
+    "det6d_vote_points": [c_int, _P, c_int, _P, c_int, c_float, c_float, c_float, _P, c_int, _P, _P],
+    "det6d_decode_boxes": [c_int, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P, _P],
+    "det6d_postprocess": [c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P],
+}
+
+#: every symbol include/det6d_ops.h declares (tests/test_boundary.py checks the export table)
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words"])
+
+_lib = None
+
+
+def lib():
+    """Load libdet6d_hip.so (after torch, so both share torch's libamdhip64.so.7)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Det6dError(
+                "libdet6d_hip.so is missing (%s). Build it with `python -m de6d_amd._build` "
+                "(or __graft_entry__.build()); there is no CPU/PyTorch fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        handle.det6d_version.restype = ctypes.c_char_p
+        handle.det6d_last_error.restype = ctypes.c_char_p
+        handle.det6d_nms_mask_words.argtypes = [c_int]
+        handle.det6d_nms_mask_words.restype = c_int64
+        _lib = handle
+    return _lib
+
+
+def version():
+    return lib().det6d_version().decode()
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc < 0:
+        raise Det6dError("%s failed: rc=%d %s" % (what, rc, lib().det6d_last_error().decode()))
+    return rc
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point on the current stream; raises on any negative status."""
+    return check(getattr(lib(), name)(*args), name)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Det6dError("det6d ops need device tensors (got a %s tensor); there is no CPU path"
+                             % t.device)
+        if t is not None and not t.is_contiguous():
+            raise Det6dError("det6d ops need contiguous tensors")

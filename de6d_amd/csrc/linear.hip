@@ -1,0 +1,248 @@
+// linear.hip — the pointwise (1x1 conv / FC) layers of the SA modules and the head as fp32 MFMA
+// GEMMs with fused prologue (neighbour gather + centre subtraction) and epilogue
+// (folded-BN shift, ReLU, empty-ball mask, max-pool over the neighbour axis).
+//
+// Replaces the unfused chain of _PointnetSAModuleFSBase.forward
+// (core/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:462-494: grouping_operation x2,
+//  cat, Conv2d, BatchNorm2d, ReLU, mask multiply, max_pool2d) and the Conv1d/BN/ReLU stacks of
+// PointHeadBox6DVote (core/pcdet/models/dense_heads/point_head_box6d_vote.py:33-78,157-169).
+//
+// Arithmetic contract (what makes the result bit-identical to oracle/det6d_oracle.c):
+//   out[r][c] = act( fma-chain_{k ascending}( A'[r][k] * W[k][c] ) + shift[c] )
+// v_mfma_f32_32x32x2_f32 is exactly that chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C)); each
+// output lives in ONE accumulator for the whole K loop (no split-K, no reassociation).
+//
+// Tiling for gfx950: 128 x BN output tile per 256-thread workgroup (4 waves), BK = 16, operands
+// staged k-major in LDS so that both MFMA fragments are conflict-free ds_read_b32
+// (A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]); next tile's global loads are issued
+// before the MFMA block of the current one (register prefetch); 16.5 KB LDS -> several
+// workgroups per CU hide each other's barriers.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
+
+__device__ __forceinline__ float relu_act(float v, int act) { return act == 1 ? (v > 0.f ? v : 0.f) : v; }
+
+template <int BN, int WMW, int WNW, int TM, int TN>
+__global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
+  static_assert(WMW * WNW == 4, "4 waves");
+  static_assert(32 * TM * WMW == BM, "row tiling");
+  static_assert(32 * TN * WNW == BN, "col tiling");
+  __shared__ float As[BK * LDA_S];
+  __shared__ float Bs[BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int R = g.rows, K = g.k, N = g.ncols;
+  const int row0 = blockIdx.x * BM;
+  const int colb = blockIdx.y * BN;
+
+  // ---- A loader: each thread owns rows (tid/4) and (tid/4 + 64), k-quad (tid%4) of the tile ----
+  const int ar = tid >> 2, akq = tid & 3;
+  const float *arow[2];
+  float csub[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = row0 + ar + 64 * i;
+    arow[i] = nullptr;
+    csub[i][0] = csub[i][1] = csub[i][2] = 0.f;
+    if (r < R) {
+      if (g.mode == DET6D_A_GROUPED) {
+        const int cj = r / g.ns;
+        const int bi = cj / g.m;
+        const int p = g.idx[r];
+        arow[i] = g.a + ((size_t)bi * g.n + p) * g.lda;
+        if (akq == 0) {
+          const float *c = g.ctr + (size_t)cj * g.ldctr;
+          csub[i][0] = c[0]; csub[i][1] = c[1]; csub[i][2] = c[2];
+        }
+      } else {
+        arow[i] = g.a + (size_t)r * g.lda;
+      }
+    }
+  }
+  // ---- B loader: BK x BN tile = 4*BN float4 ----
+  constexpr int NB4 = (BK * BN / 4 + 255) / 256;  // float4 per thread
+  constexpr int B4_PER_ROW = BN / 4;
+
+  float4 ra[2];
+  float4 rb[NB4];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + 4 * akq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (arow[i] != nullptr && k + 3 < K) v = *reinterpret_cast<const float4 *>(arow[i] + k);
+      else if (arow[i] != nullptr && k < K) {  // K % 4 != 0 tail
+        v.x = arow[i][k];
+        if (k + 1 < K) v.y = arow[i][k + 1];
+        if (k + 2 < K) v.z = arow[i][k + 2];
+      }
+      if (k0 == 0 && akq == 0) {  // grouped_xyz -= new_xyz (pointnet2_utils.py:449-450)
+        v.x = v.x - csub[i][0]; v.y = v.y - csub[i][1]; v.z = v.z - csub[i][2];
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int f = tid + 256 * i;
+      const int k = k0 + f / B4_PER_ROW;
+      const int c = colb + 4 * (f % B4_PER_ROW);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < BK * B4_PER_ROW && k < K && c + 3 < g.ldw) v = *reinterpret_cast<const float4 *>(g.w + (size_t)k * g.ldw + c);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // transposed store As[k][row]: bank = (8*akq + 2*j + row) % 32 -> 32 distinct banks per half-wave
+      float *dst = As + (4 * akq) * LDA_S + ar + 64 * i;
+      dst[0 * LDA_S] = ra[i].x;
+      dst[1 * LDA_S] = ra[i].y;
+      dst[2 * LDA_S] = ra[i].z;
+      dst[3 * LDA_S] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int f = tid + 256 * i;
+      if (f < BK * B4_PER_ROW)
+        *reinterpret_cast<float4 *>(Bs + (f / B4_PER_ROW) * BN + 4 * (f % B4_PER_ROW)) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int arow_s = wm * 32 * TM + l31;
+  const int bcol_s = wn * 32 * TN + l31;
+
+  load_tile(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    store_tile();
+    __syncthreads();
+    if (k0 + BK < K) load_tile(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[(2 * ks + kh) * LDA_S + arow_s + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * ks + kh) * BN + bcol_s + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colb + wn * 32 * TN + 32 * j + l31;
+    const bool cok = col < N;
+    const float sh = (cok && g.shift) ? g.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = row0 + wm * 32 * TM + 32 * i;  // first row of this 32x32 tile
+      if (g.pool == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (cok && row < R) g.y[(size_t)row * g.ldy + g.col0 + col] = relu_act(acc[i][j][e] + sh, g.act);
+        }
+      } else {
+        // rows of a tile: (e&3) + 8*(e>>2) + 4*kh  -> 8-row bundle q = e>>2 spans both lane halves
+        float q[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float m = relu_act(acc[i][j][4 * qq] + sh, g.act);
+#pragma unroll
+          for (int e = 1; e < 4; ++e) {
+            const float v = relu_act(acc[i][j][4 * qq + e] + sh, g.act);
+            m = v > m ? v : m;
+          }
+          const float o = __shfl_xor(m, 32);
+          q[qq] = o > m ? o : m;
+        }
+        if (g.pool == 32) {
+          float m = q[0];
+          m = q[1] > m ? q[1] : m; m = q[2] > m ? q[2] : m; m = q[3] > m ? q[3] : m;
+          const int grp = rbase / 32;
+          if (cok && kh == 0 && rbase < R) {
+            const bool live = g.cnt ? g.cnt[grp] > 0 : true;
+            g.y[(size_t)grp * g.ldy + g.col0 + col] = live ? m : 0.f;
+          }
+        } else if (g.pool == 16) {
+          const float m0 = q[1] > q[0] ? q[1] : q[0];
+          const float m1 = q[3] > q[2] ? q[3] : q[2];
+          const int grp = rbase / 16;
+          if (cok && kh == 0) {
+            if (rbase < R) {
+              const bool live = g.cnt ? g.cnt[grp] > 0 : true;
+              g.y[(size_t)grp * g.ldy + g.col0 + col] = live ? m0 : 0.f;
+            }
+            if (rbase + 16 < R) {
+              const bool live = g.cnt ? g.cnt[grp + 1] > 0 : true;
+              g.y[(size_t)(grp + 1) * g.ldy + g.col0 + col] = live ? m1 : 0.f;
+            }
+          }
+        } else {  // pool == 8
+          const int grp = rbase / 8;
+          if (cok && kh == 0) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+              if (rbase + 8 * qq < R) {
+                const bool live = g.cnt ? g.cnt[grp + qq] > 0 : true;
+                g.y[(size_t)(grp + qq) * g.ldy + g.col0 + col] = live ? q[qq] : 0.f;
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
+  if (!a || a->rows < 0 || a->k <= 0 || a->ncols <= 0 || !a->a || !a->w || !a->y) return DET6D_EINVAL;
+  if ((a->lda & 3) || (a->ldw & 3) || ((uintptr_t)a->a & 15) || ((uintptr_t)a->w & 15)) return DET6D_EINVAL;
+  if (a->k > a->lda || a->ncols > a->ldw) return DET6D_EINVAL;
+  if (a->mode == DET6D_A_GROUPED) {
+    if (!a->idx || !a->ctr || a->ns <= 0 || a->m <= 0 || a->n <= 0 || a->ldctr < 3) return DET6D_EINVAL;
+    if (a->rows % (a->m * a->ns)) return DET6D_EINVAL;
+  } else if (a->mode != DET6D_A_ROWS) {
+    return DET6D_EINVAL;
+  }
+  if (a->pool != 0 && a->pool != 8 && a->pool != 16 && a->pool != 32) return DET6D_EINVAL;
+  if (a->pool && (a->rows % a->pool)) return DET6D_EINVAL;
+  if (a->rows == 0) return DET6D_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int gm = det6d_divup(a->rows, BM);
+  if (a->ncols > 64) {
+    hipLaunchKernelGGL((linear_kernel<128, 2, 2, 2, 2>), dim3(gm, det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+  } else if (a->ncols > 32) {
+    hipLaunchKernelGGL((linear_kernel<64, 2, 2, 2, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+  } else {
+    hipLaunchKernelGGL((linear_kernel<32, 4, 1, 1, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+  }
+  return det6d_check_launch("det6d_linear");
+}

@@ -1,0 +1,353 @@
+// points.hip — the bandwidth-bound index/elementwise ops of the path (gather, group, 3-NN,
+// interpolation, point packing, vote clamp, box decode).  One thread per output element,
+// grid-stride, coalesced on the output side; all of them are HBM/L2-bound byte movers.
+//
+// Replaces core/pcdet/ops/pointnet2/pointnet2_batch/src/{sampling_gpu.cu:16-90,
+// group_points_gpu.cu:14-92, interpolate_gpu.cu:16-170}.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline dim3 grid_for(int64_t total) {
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks);
+}
+
+#define GRID_STRIDE(i, total)                                                       \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total);     \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+// out[b,c,j] = points[b,c,idx[b,j]]
+__global__ void gather_points_kernel(int64_t total, int c, int n, int m, const float *__restrict__ points,
+                                     const int *__restrict__ idx, float *__restrict__ out) {
+  GRID_STRIDE(i, total) {
+    const int j = (int)(i % m);
+    const int64_t bc = i / m;
+    const int64_t bi = bc / c;
+    out[i] = points[bc * n + idx[bi * m + j]];
+  }
+}
+
+__global__ void gather_points_grad_kernel(int64_t total, int c, int n, int m,
+                                          const float *__restrict__ grad_out,
+                                          const int *__restrict__ idx, float *__restrict__ grad_points) {
+  GRID_STRIDE(i, total) {
+    const int j = (int)(i % m);
+    const int64_t bc = i / m;
+    const int64_t bi = bc / c;
+    atomicAdd(grad_points + bc * n + idx[bi * m + j], grad_out[i]);
+  }
+}
+
+// out[b,c,p,s] = points[b,c,idx[b,p,s]]
+__global__ void group_points_kernel(int64_t total, int c, int n, int64_t ms,
+                                    const float *__restrict__ points, const int *__restrict__ idx,
+                                    float *__restrict__ out) {
+  GRID_STRIDE(i, total) {
+    const int64_t ps = i % ms;
+    const int64_t bc = i / ms;
+    const int64_t bi = bc / c;
+    out[i] = points[bc * n + idx[bi * ms + ps]];
+  }
+}
+
+__global__ void group_points_grad_kernel(int64_t total, int c, int n, int64_t ms,
+                                         const float *__restrict__ grad_out,
+                                         const int *__restrict__ idx, float *__restrict__ grad_points) {
+  GRID_STRIDE(i, total) {
+    const int64_t ps = i % ms;
+    const int64_t bc = i / ms;
+    const int64_t bi = bc / c;
+    atomicAdd(grad_points + bc * n + idx[bi * ms + ps], grad_out[i]);
+  }
+}
+
+// interpolate_gpu.cu:16-59: double running bests initialised to 1e40, strict '<' cascade.
+__global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                const float *__restrict__ known, float *__restrict__ dist2,
+                                int *__restrict__ idx) {
+  __shared__ float tile[3 * 512];
+  const int bs = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = pt < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (live) {
+    const float *u = unknown + ((size_t)bs * n + pt) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  const float *kn = known + (size_t)bs * m * 3;
+  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k0 = 0; k0 < m; k0 += 512) {
+    const int cnt = min(512, m - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += blockDim.x) tile[t] = kn[(size_t)k0 * 3 + t];
+    __syncthreads();
+    if (live) {
+      for (int kk = 0; kk < cnt; ++kk) {
+        const float d = d6_sqdist(ux - tile[kk * 3 + 0], uy - tile[kk * 3 + 1], uz - tile[kk * 3 + 2]);
+        const int k = k0 + kk;
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+    }
+  }
+  if (live) {
+    float *od = dist2 + ((size_t)bs * n + pt) * 3;
+    int *oi = idx + ((size_t)bs * n + pt) * 3;
+    od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+    oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+  }
+}
+
+// out[b,c,i] = fma(w2,p2, fma(w0,p0, w1*p1))   (contraction order: oracle/det6d_oracle.c)
+__global__ void three_interpolate_kernel(int64_t total, int c, int m, int n,
+                                         const float *__restrict__ points, const int *__restrict__ idx,
+                                         const float *__restrict__ weight, float *__restrict__ out) {
+  GRID_STRIDE(i, total) {
+    const int pt = (int)(i % n);
+    const int64_t bc = i / n;
+    const int64_t bi = bc / c;
+    const float *w = weight + (bi * n + pt) * 3;
+    const int *id = idx + (bi * n + pt) * 3;
+    const float *p = points + bc * m;
+    out[i] = D6_FMA(w[2], p[id[2]], D6_FMA(w[0], p[id[0]], w[1] * p[id[1]]));
+  }
+}
+
+__global__ void three_interpolate_grad_kernel(int64_t total, int c, int n, int m,
+                                              const float *__restrict__ grad_out,
+                                              const int *__restrict__ idx,
+                                              const float *__restrict__ weight,
+                                              float *__restrict__ grad_points) {
+  GRID_STRIDE(i, total) {
+    const int pt = (int)(i % n);
+    const int64_t bc = i / n;
+    const int64_t bi = bc / c;
+    const float *w = weight + (bi * n + pt) * 3;
+    const int *id = idx + (bi * n + pt) * 3;
+    float *gp = grad_points + bc * m;
+    const float g = grad_out[i];
+    atomicAdd(gp + id[0], g * w[0]);
+    atomicAdd(gp + id[1], g * w[1]);
+    atomicAdd(gp + id[2], g * w[2]);
+  }
+}
+
+__global__ void pack_points_kernel(int64_t total, int width, int ld, const float *__restrict__ points,
+                                   float *__restrict__ rows) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % ld);
+    const int64_t r = i / ld;
+    rows[i] = c < width ? points[r * (width + 1) + 1 + c] : 0.f;
+  }
+}
+
+__global__ void gather_rows_kernel(int64_t total, int n, int m, int ld_in, int ld_out, int ncol,
+                                   const float *__restrict__ rows_in, const int *__restrict__ idx,
+                                   float *__restrict__ rows_out) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % ncol);
+    const int64_t bj = i / ncol;
+    const int64_t bi = bj / m;
+    rows_out[bj * ld_out + c] = rows_in[(bi * n + idx[bj]) * ld_in + c];
+  }
+}
+
+__global__ void sigmoid_pow_kernel(int64_t total, const float *__restrict__ s, float gamma,
+                                   float *__restrict__ w) {
+  GRID_STRIDE(i, total) w[i] = d6_sigmoid_powf(s[i], gamma);
+}
+
+__global__ void vote_points_kernel(int64_t total, const float *__restrict__ off, int ldo,
+                                   const float *__restrict__ cand, int ldc, float rx, float ry, float rz,
+                                   float *__restrict__ vote, int ldv, float *__restrict__ off_out) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % 3);
+    const int64_t r = i / 3;
+    const float R = c == 0 ? rx : (c == 1 ? ry : rz);
+    float o = off[r * ldo + c];
+    o = o > -R ? o : -R;
+    o = o < R ? o : R;
+    if (off_out) off_out[r * 3 + c] = o;
+    vote[r * ldv + c] = cand[r * ldc + c] + o;
+  }
+}
+
+// box_coder_utils.py:589-603,622-680 (PointBinResidual6DCoder.decode_torch, use_mean_size=False)
+__global__ void decode_boxes_kernel(int rows, int nbin, int ground_aware, int minus, float thr,
+                                    float fac, float per_bin, const float *__restrict__ code, int ldcode,
+                                    const float *__restrict__ pts, int ldp, float *__restrict__ boxes) {
+  GRID_STRIDE(r, rows) {
+    const float *c = code + r * ldcode;
+    const float *p = pts + r * ldp;
+    float *o = boxes + r * 9;
+    o[0] = c[0] + p[0];
+    o[1] = c[1] + p[1];
+    o[2] = c[2] + p[2];
+    o[3] = d6_expf(c[3]);
+    o[4] = d6_expf(c[4]);
+    o[5] = d6_expf(c[5]);
+    const float *bin = c + 6, *res = c + 6 + nbin, *gr = c + 6 + 2 * nbin;
+    int am = 0;
+    float bv = bin[0];
+    for (int i = 1; i < nbin; ++i) {
+      const float v = bin[i];
+      if (v > bv) { bv = v; am = i; }
+    }
+    o[6] = ((float)am + res[am]) * per_bin;
+    if (ground_aware) {
+      const bool no_pitch = d6_sigmoidf(gr[0]) < 0.5f;
+      float pitch = minus ? gr[1] * fac : (-thr) - gr[1] * fac;
+      if (no_pitch) pitch = 0.f;
+      o[7] = pitch;
+    } else {
+      o[7] = gr[0];
+    }
+    o[8] = 0.f;
+  }
+}
+
+}  // namespace
+
+#define S(x) ((hipStream_t)(x))
+
+DET6D_API int det6d_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                                  float *out, det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || !points || !idx || !out) return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * c * npoints;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(gather_points_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, n,
+                     npoints, points, idx, out);
+  return det6d_check_launch("det6d_gather_points");
+}
+
+DET6D_API int det6d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                       const int *idx, float *grad_points, det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || !grad_out || !idx || !grad_points) return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * c * npoints;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(gather_points_grad_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, n,
+                     npoints, grad_out, idx, grad_points);
+  return det6d_check_launch("det6d_gather_points_grad");
+}
+
+DET6D_API int det6d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                 const int *idx, float *out, det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0 || !points || !idx || !out) return DET6D_EINVAL;
+  const int64_t ms = (int64_t)npoints * nsample;
+  const int64_t total = (int64_t)b * c * ms;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(group_points_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, n, ms,
+                     points, idx, out);
+  return det6d_check_launch("det6d_group_points");
+}
+
+DET6D_API int det6d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                      const float *grad_out, const int *idx, float *grad_points,
+                                      det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0 || !grad_out || !idx || !grad_points)
+    return DET6D_EINVAL;
+  const int64_t ms = (int64_t)npoints * nsample;
+  const int64_t total = (int64_t)b * c * ms;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(group_points_grad_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, n,
+                     ms, grad_out, idx, grad_points);
+  return det6d_check_launch("det6d_group_points_grad");
+}
+
+DET6D_API int det6d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                             int *idx, det6d_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0 || !unknown || !known || !dist2 || !idx) return DET6D_EINVAL;
+  if (b == 0 || n == 0) return DET6D_OK;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(det6d_divup(n, kBlock), b), dim3(kBlock), 0, S(stream), n, m,
+                     unknown, known, dist2, idx);
+  return det6d_check_launch("det6d_three_nn");
+}
+
+DET6D_API int det6d_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                      const float *weight, float *out, det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || m < 0 || !points || !idx || !weight || !out) return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * c * n;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(three_interpolate_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, m,
+                     n, points, idx, weight, out);
+  return det6d_check_launch("det6d_three_interpolate");
+}
+
+DET6D_API int det6d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                           const int *idx, const float *weight, float *grad_points,
+                                           det6d_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || m < 0 || !grad_out || !idx || !weight || !grad_points) return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * c * n;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c,
+                     n, m, grad_out, idx, weight, grad_points);
+  return det6d_check_launch("det6d_three_interpolate_grad");
+}
+
+DET6D_API int det6d_pack_points(int total, int cin, const float *points, int ld, float *rows,
+                                det6d_stream_t stream) {
+  if (total < 0 || cin < 0 || ld < 3 + cin || !points || !rows) return DET6D_EINVAL;
+  const int64_t elems = (int64_t)total * ld;
+  if (elems == 0) return DET6D_OK;
+  hipLaunchKernelGGL(pack_points_kernel, grid_for(elems), dim3(kBlock), 0, S(stream), elems, 3 + cin, ld,
+                     points, rows);
+  return det6d_check_launch("det6d_pack_points");
+}
+
+DET6D_API int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol, const float *rows_in,
+                                const int *idx, float *rows_out, det6d_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0 || ncol < 0 || ncol > ld_in || ncol > ld_out || !rows_in || !idx || !rows_out)
+    return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * m * ncol;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, n, m, ld_in,
+                     ld_out, ncol, rows_in, idx, rows_out);
+  return det6d_check_launch("det6d_gather_rows");
+}
+
+DET6D_API int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,
+                                det6d_stream_t stream) {
+  if (count < 0 || !scores || !weights) return DET6D_EINVAL;
+  if (count == 0) return DET6D_OK;
+  hipLaunchKernelGGL(sigmoid_pow_kernel, grid_for(count), dim3(kBlock), 0, S(stream), (int64_t)count,
+                     scores, gamma, weights);
+  return det6d_check_launch("det6d_sigmoid_pow");
+}
+
+DET6D_API int det6d_vote_points(int rows, const float *off, int ldo, const float *cand, int ldc, float rx,
+                                float ry, float rz, float *vote, int ldv, float *off_out,
+                                det6d_stream_t stream) {
+  if (rows < 0 || !off || !cand || !vote || ldo < 3 || ldc < 3 || ldv < 3) return DET6D_EINVAL;
+  if (rows == 0) return DET6D_OK;
+  const int64_t total = (int64_t)rows * 3;
+  hipLaunchKernelGGL(vote_points_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, off, ldo,
+                     cand, ldc, rx, ry, rz, vote, ldv, off_out);
+  return det6d_check_launch("det6d_vote_points");
+}
+
+DET6D_API int det6d_decode_boxes(int rows, int nbin, int ground_aware, int minus, float threshold_rad,
+                                 float factor_rad, const float *code, int ldcode, const float *pts, int ldp,
+                                 float *boxes, det6d_stream_t stream) {
+  if (rows < 0 || nbin <= 0 || !code || !pts || !boxes || ldp < 3 ||
+      ldcode < 6 + 2 * nbin + (ground_aware ? 2 : 1))
+    return DET6D_EINVAL;
+  if (rows == 0) return DET6D_OK;
+  const float per_bin = (float)(3.14159265358979323846 * 2.0 / (double)nbin);
+  hipLaunchKernelGGL(decode_boxes_kernel, grid_for(rows), dim3(kBlock), 0, S(stream), rows, nbin,
+                     ground_aware, minus, threshold_rad, factor_rad, per_bin, code, ldcode, pts, ldp, boxes);
+  return det6d_check_launch("det6d_decode_boxes");
+}

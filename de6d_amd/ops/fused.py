@@ -1,0 +1,109 @@
+"""Tensor-level wrappers of the fused engine entry points of libdet6d_hip.so
+(include/det6d_ops.h, section "fused engine ops").  Outputs are caller- or wrapper-allocated
+device tensors; every call is asynchronous on the current stream."""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+
+def pack_points(points, ld):
+    """(B*N, 1+3+C) [b,x,y,z,f..] -> rows (B*N, ld) [x,y,z,f..,0..]  (pointnet2_backbone.py:193-224)"""
+    L.require_cuda(points)
+    total, width = points.shape
+    rows = torch.empty((total, ld), dtype=torch.float32, device=points.device)
+    L.call("det6d_pack_points", total, width - 4, L.ptr(points), ld, L.ptr(rows), L.stream_ptr())
+    return rows
+
+
+def gather_rows(rows_in, idx, ncol, out):
+    """out[b,j,:ncol] = rows_in[b, idx[b,j], :ncol]"""
+    L.require_cuda(rows_in, idx, out)
+    b, n, ld_in = rows_in.shape
+    m = idx.shape[1]
+    L.call("det6d_gather_rows", b, n, m, ld_in, out.shape[-1], ncol, L.ptr(rows_in), L.ptr(idx), L.ptr(out),
+           L.stream_ptr())
+    return out
+
+
+def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None, cnt=None, pool=0):
+    """out[..., col0:col0+ncols] = act(A' @ W + shift) with optional neighbour gather / max-pool.
+
+    a:   (R, lda) rows, or (B, n, lda) point rows when `idx` (B, m, ns) is given
+    w:   (K_rows, ldw) weights, BN folded;  shift: (ncols,) or None;  act: 0 none / 1 ReLU
+    out: (R or R/pool, ldy)
+    """
+    L.require_cuda(a, w, shift, out, idx, ctr, cnt)
+    g = L.LinearArgs()
+    g.k = w.shape[0] if k is None else k
+    g.ncols = w.shape[1] if ncols is None else ncols
+    g.a, g.lda = a.data_ptr(), a.shape[-1]
+    g.w, g.ldw = w.data_ptr(), w.shape[1]
+    g.shift = shift.data_ptr() if shift is not None else None
+    g.act = act
+    g.y, g.ldy, g.col0 = out.data_ptr(), out.shape[-1], col0
+    if idx is not None:
+        bsz, m, ns = idx.shape
+        g.mode, g.rows = 1, bsz * m * ns
+        g.n, g.m, g.ns = a.shape[1], m, ns
+        g.idx = idx.data_ptr()
+        g.ctr, g.ldctr = ctr.data_ptr(), ctr.shape[-1]
+    else:
+        g.mode, g.rows = 0, a.numel() // a.shape[-1]
+    g.pool = pool
+    g.cnt = cnt.data_ptr() if cnt is not None else None
+    L.call("det6d_linear", ctypes.byref(g), L.stream_ptr())
+    return out
+
+
+def sigmoid_pow(scores, gamma, out=None):
+    L.require_cuda(scores)
+    out = torch.empty_like(scores) if out is None else out
+    L.call("det6d_sigmoid_pow", scores.numel(), L.ptr(scores), float(gamma), L.ptr(out), L.stream_ptr())
+    return out
+
+
+def vote_points(off, cand, rng, vote, off_out=None):
+    L.require_cuda(off, cand, vote, off_out)
+    rows = off.numel() // off.shape[-1]
+    L.call("det6d_vote_points", rows, L.ptr(off), off.shape[-1], L.ptr(cand), cand.shape[-1],
+           float(rng[0]), float(rng[1]), float(rng[2]), L.ptr(vote), vote.shape[-1], L.ptr(off_out),
+           L.stream_ptr())
+    return vote
+
+
+def decode_boxes(code, pts, nbin, ground_aware, minus, threshold_rad, factor_rad, out=None):
+    L.require_cuda(code, pts)
+    rows = code.numel() // code.shape[-1]
+    out = torch.empty((rows, 9), dtype=torch.float32, device=code.device) if out is None else out
+    L.call("det6d_decode_boxes", rows, nbin, int(ground_aware), int(minus), float(threshold_rad),
+           float(factor_rad), L.ptr(code), code.shape[-1], L.ptr(pts), pts.shape[-1], L.ptr(out), L.stream_ptr())
+    return out
+
+
+def postprocess(cls, boxes, b, score_thr, pre_max, post_max, nms_thr):
+    L.require_cuda(cls, boxes)
+    p = cls.shape[0] // b
+    dev = cls.device
+    ob = torch.empty((b, post_max, 9), dtype=torch.float32, device=dev)
+    os_ = torch.empty((b, post_max), dtype=torch.float32, device=dev)
+    ol = torch.empty((b, post_max), dtype=torch.int32, device=dev)
+    oi = torch.empty((b, post_max), dtype=torch.int32, device=dev)
+    oc = torch.empty((b,), dtype=torch.int32, device=dev)
+    L.call("det6d_postprocess", b, p, cls.shape[1], L.ptr(cls), L.ptr(boxes), float(score_thr), pre_max,
+           post_max, float(nms_thr), L.ptr(ob), L.ptr(os_), L.ptr(ol), L.ptr(oi), L.ptr(oc), L.stream_ptr())
+    return ob, os_, ol, oi, oc
+
+
+def nms_device(boxes, thresh, normal=False):
+    """device-resident NMS: returns (keep int64 (K,), num_keep int32 (1,)) without a host sync"""
+    L.require_cuda(boxes)
+    k = boxes.shape[0]
+    words = max(int(L.lib().det6d_nms_mask_words(k)), 1)
+    mask = torch.empty((words,), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((max(k, 1),), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    L.call("det6d_nms_normal" if normal else "det6d_nms", k, L.ptr(boxes), float(thresh), L.ptr(mask),
+           L.ptr(keep), L.ptr(num), L.stream_ptr())
+    return keep, num

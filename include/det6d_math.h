@@ -48,8 +48,14 @@ D6_HD uint32_t d6_f2bits(float f) {
 D6_HD float d6_fabsf(float x) { return d6_bits2f(d6_f2bits(x) & 0x7fffffffu); }
 
 /* fminf/fmaxf with the CUDA/C99 rule "if one operand is NaN return the other". */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* v_min_f32 / v_max_f32 implement exactly this rule */
+D6_HD float d6_fminf(float a, float b) { return __builtin_fminf(a, b); }
+D6_HD float d6_fmaxf(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
 D6_HD float d6_fminf(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 D6_HD float d6_fmaxf(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+#endif
 
 /* round-to-nearest-even to an integer valued float, |x| < 2^22 */
 D6_HD float d6_rintf_small(float x) {

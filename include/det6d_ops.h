@@ -213,7 +213,7 @@ int det6d_decode_boxes(int rows, int nbin, int ground_aware, int minus, float th
  *   stable descending sort, top pre_max, rotated NMS (dims 0..6) at nms_thr, first post_max.
  * Outputs (device): out_boxes (B,post_max,9), out_scores (B,post_max), out_labels (B,post_max)
  * i32 1-based, out_index (B,post_max) i32 = index of the kept box inside its scene, out_count (B).
- * P <= 1024. Equal scores are ordered by ascending original index (the reference uses an
+ * P <= 512 (suppression matrix lives in LDS). Equal scores are ordered by ascending original index (the reference uses an
  * unstable torch sort there). */
 int det6d_postprocess(int b, int p, int ncls, const float *cls, const float *boxes, float score_thr,
                       int pre_max, int post_max, float nms_thr, float *out_boxes, float *out_scores,

@@ -1,0 +1,249 @@
+"""GPU parity tests: every C-ABI op of libdet6d_hip.so (through the reference-shaped module
+functions) against the CPU oracle on the same seeded inputs.  Bit-exact for indices, masks and
+for everything computed with the shared deterministic arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import make_batch, random_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from de6d_amd.ops import pointnet2_batch_hip, iou3d_nms_hip, fused
+    return pointnet2_batch_hip, iou3d_nms_hip, fused
+
+
+def hip_fps(pn, xyz, m, weights=None):
+    b, n, _ = xyz.shape
+    x = dev(xyz)
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device="cuda")
+    idx = torch.zeros((b, m), dtype=torch.int32, device="cuda")
+    if weights is None:
+        pn.farthest_point_sampling_wrapper(b, n, m, x, temp, idx)
+    else:
+        pn.furthest_point_sampling_weights_wrapper(b, n, m, x, dev(weights), temp, idx)
+    return idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 16384, 4096), (2, 4096, 512), (3, 512, 256), (2, 1000, 100),
+                                   (2, 100, 37), (1, 7, 7), (1, 1, 1), (2, 3000, 64), (1, 20000, 50)])
+def test_fps_bit_exact(ext, oracle_ops, b, n, m):
+    pn = ext[0]
+    xyz = make_batch(10, b, n, dup_frac=0.1)[..., :3]
+    np.testing.assert_array_equal(hip_fps(pn, xyz, m), oracle_ops.fps(xyz, m))
+
+
+def test_fps_all_duplicates(ext, oracle_ops):
+    """every point identical: the pick is decided purely by the tie rule (bitrev(k mod S), k)"""
+    pn = ext[0]
+    xyz = np.ones((1, 4096, 3), np.float32)
+    np.testing.assert_array_equal(hip_fps(pn, xyz, 64), oracle_ops.fps(xyz, 64))
+    xyz = np.ones((1, 300, 3), np.float32)
+    np.testing.assert_array_equal(hip_fps(pn, xyz, 20), oracle_ops.fps(xyz, 20))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 512), (2, 512, 256), (1, 16384, 300), (2, 777, 99), (1, 40, 9)])
+def test_fps_weights_bit_exact(ext, oracle_ops, b, n, m):
+    pn = ext[0]
+    xyz = make_batch(20, b, n, dup_frac=0.1)[..., :3]
+    rng = np.random.default_rng(5)
+    w = (1.0 / (1.0 + np.exp(-rng.normal(size=(b, n)) * 3))).astype(np.float32)
+    w[:, ::17] = 0.0          # exercises max(w, 1e-12) in double
+    w[:, 5::29] = 1e-13
+    w[:, 3::31] = w[:, 2:-1:31][:, :w[:, 3::31].shape[1]]  # equal weights -> ties
+    np.testing.assert_array_equal(hip_fps(pn, xyz, m, w), oracle_ops.fps_weights(xyz, w, m))
+
+
+def test_gather_and_group(ext, oracle_ops):
+    pn = ext[0]
+    rng = np.random.default_rng(1)
+    b, c, n, m, ns = 2, 5, 300, 40, 16
+    pts = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m)).astype(np.int32)
+    out = torch.empty((b, c, m), device="cuda")
+    pn.gather_points_wrapper(b, c, n, m, dev(pts), dev(idx), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle_ops.gather_points(pts, idx))
+    gidx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    gout = torch.empty((b, c, m, ns), device="cuda")
+    pn.group_points_wrapper(b, c, n, m, ns, dev(pts), dev(gidx), gout)
+    np.testing.assert_array_equal(gout.cpu().numpy(), oracle_ops.group_points(pts, gidx))
+    # backward scatters: atomic order differs from the sequential oracle -> tolerance
+    go = rng.normal(size=(b, c, m)).astype(np.float32)
+    gp = torch.zeros((b, c, n), device="cuda")
+    pn.gather_points_grad_wrapper(b, c, n, m, dev(go), dev(idx), gp)
+    np.testing.assert_allclose(gp.cpu().numpy(), oracle_ops.gather_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    ggo = rng.normal(size=(b, c, m, ns)).astype(np.float32)
+    ggp = torch.zeros((b, c, n), device="cuda")
+    pn.group_points_grad_wrapper(b, c, n, m, ns, dev(ggo), dev(gidx), ggp)
+    np.testing.assert_allclose(ggp.cpu().numpy(), oracle_ops.group_points_grad(ggo, gidx, n), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m,r_in,r_out,ns", [(16384, 512, 0.0, 0.2, 16), (16384, 512, 0.2, 0.8, 32),
+                                               (4096, 1024, 0.8, 1.6, 32), (1024, 512, 1.6, 4.8, 32),
+                                               (512, 256, 0.0, 6.4, 32), (100, 30, 0.0, 0.01, 8),
+                                               (70, 9, 0.0, 100.0, 128)])
+def test_ball_query_variants(ext, oracle_ops, n, m, r_in, r_out, ns):
+    pn = ext[0]
+    b = 2
+    xyz = make_batch(30, b, n, dup_frac=0.05)[..., :3]
+    new_xyz = np.ascontiguousarray(xyz[:, :m] + np.float32(0.01))
+    new_xyz[:, 0] = 1000.0  # a centre with no neighbours at all
+    x, q = dev(xyz), dev(new_xyz)
+    # dilated
+    cnt = torch.zeros((b, m), dtype=torch.int32, device="cuda")
+    idx = torch.zeros((b, m, ns), dtype=torch.int32, device="cuda")
+    pn.ball_query_dilated_wrapper(b, n, m, r_in, r_out, ns, q, x, cnt, idx)
+    ocnt, oidx = oracle_ops.ball_query_dilated(r_in, r_out, ns, xyz, new_xyz)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), ocnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    # cnt
+    cnt.zero_(); idx.zero_()
+    pn.ball_query_cnt_wrapper(b, n, m, r_out, ns, q, x, cnt, idx)
+    ocnt, oidx = oracle_ops.ball_query_cnt(r_out, ns, xyz, new_xyz)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), ocnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    # plain
+    idx.zero_()
+    pn.ball_query_wrapper(b, n, m, r_out, ns, q, x, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle_ops.ball_query(r_out, ns, xyz, new_xyz))
+
+
+def test_three_nn_interpolate(ext, oracle_ops):
+    pn = ext[0]
+    b, n, m, c = 2, 1500, 700, 6
+    unknown = make_batch(40, b, n)[..., :3]
+    known = np.ascontiguousarray(unknown[:, :m])   # exact zeros + duplicates -> ties
+    d2 = torch.empty((b, n, 3), device="cuda")
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device="cuda")
+    pn.three_nn_wrapper(b, n, m, dev(unknown), dev(known), d2, idx)
+    od2, oidx = oracle_ops.three_nn(unknown, known)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    np.testing.assert_array_equal(d2.cpu().numpy(), od2)
+    rng = np.random.default_rng(3)
+    feats = rng.normal(size=(b, c, m)).astype(np.float32)
+    w = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    out = torch.empty((b, c, n), device="cuda")
+    pn.three_interpolate_wrapper(b, c, m, n, dev(feats), idx, dev(w), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle_ops.three_interpolate(feats, oidx, w))
+    go = rng.normal(size=(b, c, n)).astype(np.float32)
+    gp = torch.zeros((b, c, m), device="cuda")
+    pn.three_interpolate_grad_wrapper(b, c, n, m, dev(go), idx, dev(w), gp)
+    np.testing.assert_allclose(gp.cpu().numpy(), oracle_ops.three_interpolate_grad(go, oidx, w, m), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [1, 2, 63, 64, 65, 256, 512, 700])
+def test_iou_and_nms_bit_exact(ext, oracle_ops, k):
+    _, nm, fused = ext
+    boxes = random_boxes(k, k, spread=8.0 + k / 8)
+    if k > 4:
+        boxes[3] = boxes[1]                 # identical boxes
+        boxes[4, 3:5] = 0.0                 # zero-area box
+    bd = dev(boxes)
+    iou = torch.zeros((k, k), device="cuda")
+    nm.boxes_iou_bev_gpu(bd, bd, iou)
+    np.testing.assert_array_equal(iou.cpu().numpy(), oracle_ops.boxes_iou_bev(boxes, boxes))
+    ov = torch.zeros((k, k), device="cuda")
+    nm.boxes_overlap_bev_gpu(bd, bd, ov)
+    np.testing.assert_array_equal(ov.cpu().numpy(), oracle_ops.boxes_overlap_bev(boxes, boxes))
+    for thr in (0.01, 0.1, 0.7):
+        keep = torch.zeros(k, dtype=torch.int64)
+        num = nm.nms_gpu(bd, keep, thr)
+        np.testing.assert_array_equal(keep[:num].numpy(), oracle_ops.nms(boxes, thr))
+        num = nm.nms_normal_gpu(bd, keep, thr)
+        np.testing.assert_array_equal(keep[:num].numpy(), oracle_ops.nms(boxes, thr, normal=True))
+    kd, nd = fused.nms_device(bd, 0.1)
+    np.testing.assert_array_equal(kd[:int(nd.item())].cpu().numpy(), oracle_ops.nms(boxes, 0.1))
+
+
+@pytest.mark.parametrize("rows,k,n", [(256, 16, 16), (1000, 132, 64), (384, 260, 256), (128, 68, 32),
+                                      (4096, 512, 1024), (77, 4, 3), (640, 36, 96)])
+def test_linear_rows_bit_exact(ext, oracle_ops, rows, k, n):
+    fused = ext[2]
+    rng = np.random.default_rng(rows + k)
+    lda = (k + 3) // 4 * 4
+    ldw = (n + 3) // 4 * 4
+    a = rng.normal(size=(rows, lda)).astype(np.float32)
+    w = (rng.normal(size=(k, ldw)) / np.sqrt(k)).astype(np.float32)
+    shift = rng.normal(size=(n,)).astype(np.float32)
+    for act in (0, 1):
+        out = torch.zeros((rows, n + 5), device="cuda")
+        fused.linear(dev(a), dev(w), dev(shift), act, out, k=k, ncols=n, col0=2)
+        ref = np.zeros((rows, n + 5), np.float32)
+        oracle_ops.linear(a, w[:, :n], shift, act, k=k, out=ref, col0=2)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,m,ns,c,n1", [(512, 64, 16, 1, 16), (1024, 96, 32, 64, 64), (300, 40, 32, 128, 128),
+                                         (256, 24, 16, 256, 256), (200, 10, 8, 5, 40)])
+def test_linear_grouped_pool_bit_exact(ext, oracle_ops, n, m, ns, c, n1):
+    fused = ext[2]
+    b = 2
+    rng = np.random.default_rng(n + m)
+    ld = (3 + c + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3 + c] = rng.normal(size=(b, n, 3 + c))
+    ctr = np.zeros((b, m, 4), np.float32)
+    ctr[..., :3] = rng.normal(size=(b, m, 3))
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, 3, (b, m)).astype(np.int32)
+    w = (rng.normal(size=(ld, n1)) / np.sqrt(ld)).astype(np.float32)
+    w[3 + c:] = 0
+    shift = rng.normal(size=(n1,)).astype(np.float32)
+    # layer 1 unpooled (grouped gather + centre subtraction)
+    out = torch.zeros((b * m * ns, n1), device="cuda")
+    fused.linear(dev(rows), dev(w), dev(shift), 1, out, idx=dev(idx), ctr=dev(ctr))
+    ref = oracle_ops.linear(rows, w, shift, 1, idx=idx, ctr=ctr)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # pooled + masked
+    outp = torch.zeros((b * m, n1 + 4), device="cuda")
+    fused.linear(dev(rows), dev(w), dev(shift), 1, outp, idx=dev(idx), ctr=dev(ctr), cnt=dev(cnt), pool=ns, col0=4)
+    refp = np.zeros((b * m, n1 + 4), np.float32)
+    oracle_ops.linear(rows, w, shift, 1, idx=idx, ctr=ctr, cnt=cnt, pool=ns, out=refp, col0=4)
+    np.testing.assert_array_equal(outp.cpu().numpy(), refp)
+
+
+def test_head_elementwise_bit_exact(ext, oracle_ops):
+    fused = ext[2]
+    rng = np.random.default_rng(9)
+    r = 777
+    s = (rng.normal(size=(r,)) * 4).astype(np.float32)
+    for gamma in (1.0, 0.5, 2.0):
+        np.testing.assert_array_equal(fused.sigmoid_pow(dev(s), gamma).cpu().numpy(), oracle_ops.sigmoid_pow(s, gamma))
+    off = (rng.normal(size=(r, 4)) * 3).astype(np.float32)
+    cand = rng.normal(size=(r, 4)).astype(np.float32) * 10
+    vote = torch.zeros((r, 3), device="cuda")
+    offo = torch.zeros((r, 3), device="cuda")
+    fused.vote_points(dev(off), dev(cand), (3.0, 3.0, 2.0), vote, offo)
+    ov, oo = oracle_ops.vote_points(off, cand, (3.0, 3.0, 2.0))
+    np.testing.assert_array_equal(vote.cpu().numpy(), ov)
+    np.testing.assert_array_equal(offo.cpu().numpy(), oo)
+    code = rng.normal(size=(r, 32)).astype(np.float32)
+    pts = rng.normal(size=(r, 3)).astype(np.float32) * 20
+    thr, fac = np.float32(np.deg2rad(10.0)), np.float32(np.deg2rad(45.0))
+    got = fused.decode_boxes(dev(code), dev(pts), 12, True, False, thr, fac).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle_ops.decode_boxes(code, pts))
+
+
+@pytest.mark.parametrize("p,ncls", [(256, 1), (256, 3), (512, 1), (100, 2)])
+def test_postprocess_bit_exact(ext, oracle_ops, p, ncls):
+    fused = ext[2]
+    b = 3
+    rng = np.random.default_rng(p + ncls)
+    cls = (rng.normal(size=(b * p, ncls)) * 2 - 1).astype(np.float32)
+    cls[5] = cls[9]  # equal scores -> stable order
+    boxes = np.zeros((b * p, 9), np.float32)
+    boxes[:, :7] = random_boxes(1, b * p, spread=40.0)
+    boxes[:, 7] = rng.normal(size=b * p) * 0.1
+    cls[p:2 * p] = -10.0  # a scene with nothing above threshold
+    got = fused.postprocess(dev(cls), dev(boxes), b, 0.1, 512, 100, 0.01)
+    ref = oracle_ops.postprocess(cls, boxes, b, 0.1, 512, 100, 0.01)
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g.cpu().numpy(), r)
+    assert ref[4][1] == 0 and ref[4][0] > 0
