@@ -1,0 +1,16 @@
+"""Det6D detector (core/pcdet/models/detectors/det6d.py:4-30): backbone_3d -> point_head ->
+post_processing.  Inference only; the training loss branch (:14-30) is out of scope."""
+from .detector3d_template import Detector3DTemplate
+
+
+class Det6D(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        if self.training:
+            raise NotImplementedError('Det6D on HIP is an inference engine: call .eval() (training is out of scope)')
+        for module in self.module_list:
+            batch_dict = module(batch_dict)
+        return self.post_processing(batch_dict)
