@@ -8,6 +8,10 @@ import torch
 from .. import _lib as L
 
 
+#: when set to a list, linear() appends (start_event, end_event) recorded on the launch stream
+LINEAR_EVENTS = None
+
+
 def pack_points(points, ld):
     """(B*N, 1+3+C) [b,x,y,z,f..] -> rows (B*N, ld) [x,y,z,f..,0..]  (pointnet2_backbone.py:193-224)"""
     L.require_cuda(points)
@@ -53,6 +57,13 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
         g.mode, g.rows = 0, a.numel() // a.shape[-1]
     g.pool = pool
     g.cnt = cnt.data_ptr() if cnt is not None else None
+    if LINEAR_EVENTS is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call("det6d_linear", ctypes.byref(g), L.stream_ptr())
+        e1.record()
+        LINEAR_EVENTS.append((e0, e1, g.rows, g.k, g.ncols))
+        return out
     L.call("det6d_linear", ctypes.byref(g), L.stream_ptr())
     return out
 

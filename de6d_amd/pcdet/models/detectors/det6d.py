@@ -14,3 +14,10 @@ class Det6D(Detector3DTemplate):
         for module in self.module_list:
             batch_dict = module(batch_dict)
         return self.post_processing(batch_dict)
+
+    def forward_async(self, batch_dict):
+        """enqueue one full pass on the current stream without blocking the host; pair with
+        finalize().  Needs the fused post-processing route (class-agnostic nms_gpu, <= 512 boxes)."""
+        for module in self.module_list:
+            batch_dict = module(batch_dict)
+        return self.post_processing_async(batch_dict)

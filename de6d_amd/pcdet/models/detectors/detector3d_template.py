@@ -123,13 +123,8 @@ class Detector3DTemplate(nn.Module):
             raise NotImplementedError('MULTI_CLASSES_NMS is not used by Det6D configs')
         pred_dicts = []
         if fast:
-            boxes, scores, labels, index, count = fused.postprocess(
-                cls_preds.contiguous(), box_preds.contiguous(), batch_size, cfg.SCORE_THRESH,
-                nms_cfg.NMS_PRE_MAXSIZE, nms_cfg.NMS_POST_MAXSIZE, nms_cfg.NMS_THRESH)
-            counts = count.cpu().tolist()  # the only host sync of the forward pass
-            for i, k in enumerate(counts):
-                pred_dicts.append({'pred_boxes': boxes[i, :k], 'pred_scores': scores[i, :k],
-                                   'pred_labels': labels[i, :k].long()})
+            handle = self.post_processing_async(batch_dict)
+            pred_dicts = self.finalize(handle)
         else:  # generic per-scene route through the op-level API (same semantics)
             for i in range(batch_size):
                 if batch_dict.get('batch_index', None) is not None:
@@ -150,6 +145,32 @@ class Detector3DTemplate(nn.Module):
                 recall_dict = self.generate_recall_record(pd['pred_boxes'], recall_dict, i, batch_dict,
                                                           cfg.RECALL_THRESH_LIST)
         return pred_dicts, recall_dict
+
+    def post_processing_async(self, batch_dict):
+        """launch the fused post-processing kernel and an async copy of the per-scene counts;
+        nothing here blocks the host (finalize() does)"""
+        cfg = self.model_cfg.POST_PROCESSING
+        nms_cfg = cfg.NMS_CONFIG
+        boxes, scores, labels, index, count = fused.postprocess(
+            batch_dict['batch_cls_preds'].contiguous(), batch_dict['batch_box_preds'].contiguous(),
+            batch_dict['batch_size'], cfg.SCORE_THRESH, nms_cfg.NMS_PRE_MAXSIZE, nms_cfg.NMS_POST_MAXSIZE,
+            nms_cfg.NMS_THRESH)
+        count_host = torch.empty(count.shape, dtype=count.dtype, pin_memory=True)
+        count_host.copy_(count, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return dict(boxes=boxes, scores=scores, labels=labels, index=index, count=count, count_host=count_host,
+                    done=done)
+
+    @staticmethod
+    def finalize(handle):
+        """wait for one forward pass and slice its detections: the only host sync of a pass"""
+        handle['done'].synchronize()
+        out = []
+        for i, k in enumerate(handle['count_host'].tolist()):
+            out.append({'pred_boxes': handle['boxes'][i, :k], 'pred_scores': handle['scores'][i, :k],
+                        'pred_labels': handle['labels'][i, :k].long()})
+        return out
 
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
