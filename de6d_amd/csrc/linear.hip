@@ -23,14 +23,14 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BK = 16;
-constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
 
 __device__ __forceinline__ float relu_act(float v, int act) { return act == 1 ? (v > 0.f ? v : 0.f) : v; }
 
-template <int BN, int WMW, int WNW, int TM, int TN>
+template <int BM, int BN, int WMW, int WNW, int TM, int TN>
 __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
+  constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
+  constexpr int NA = BM / 64;    // A rows per thread
   static_assert(WMW * WNW == 4, "4 waves");
   static_assert(32 * TM * WMW == BM, "row tiling");
   static_assert(32 * TN * WNW == BN, "col tiling");
@@ -45,12 +45,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   const int row0 = blockIdx.x * BM;
   const int colb = blockIdx.y * BN;
 
-  // ---- A loader: each thread owns rows (tid/4) and (tid/4 + 64), k-quad (tid%4) of the tile ----
+  // ---- A loader: each thread owns rows (tid/4) [and (tid/4 + 64)], k-quad (tid%4) of the tile ----
   const int ar = tid >> 2, akq = tid & 3;
-  const float *arow[2];
-  float csub[2][3];
+  const float *arow[NA];
+  float csub[NA][3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int r = row0 + ar + 64 * i;
     arow[i] = nullptr;
     csub[i][0] = csub[i][1] = csub[i][2] = 0.f;
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   constexpr int NB4 = (BK * BN / 4 + 255) / 256;  // float4 per thread
   constexpr int B4_PER_ROW = BN / 4;
 
-  float4 ra[2];
+  float4 ra[NA];
   float4 rb[NB4];
 
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int k = k0 + 4 * akq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (arow[i] != nullptr && k + 3 < K) v = *reinterpret_cast<const float4 *>(arow[i] + k);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       // transposed store As[k][row]: bank = (8*akq + 2*j + row) % 32 -> 32 distinct banks per half-wave
       float *dst = As + (4 * akq) * LDA_S + ar + 64 * i;
       dst[0 * LDA_S] = ra[i].x;
@@ -236,13 +236,22 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   if (a->pool && (a->rows % a->pool)) return DET6D_EINVAL;
   if (a->rows == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int gm = det6d_divup(a->rows, BM);
+  const int gm = det6d_divup(a->rows, 128);
   if (a->ncols > 64) {
-    hipLaunchKernelGGL((linear_kernel<128, 2, 2, 2, 2>), dim3(gm, det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+    // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
+    // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles
+    if (gm * det6d_divup(a->ncols, 128) < 256)
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64), det6d_divup(a->ncols, 64)),
+                         dim3(256), 0, s, *a);
+    else
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm, det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
-    hipLaunchKernelGGL((linear_kernel<64, 2, 2, 2, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+    if (gm < 128)
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64), 1), dim3(256), 0, s, *a);
+    else
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
   } else {
-    hipLaunchKernelGGL((linear_kernel<32, 4, 1, 1, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
   }
   return det6d_check_launch("det6d_linear");
 }
