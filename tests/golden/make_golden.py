@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the authoring container (needs /root/reference and oracle/_ref); the fixtures it
+writes are data (inputs + expected outputs) and are what travels to the GPU box.
+
+  nms_ref.npz      (boxes, thr) -> IoU matrices from the reference's OWN iou3d_cpu.cpp (oracle/_ref)
+                   + keep lists from the greedy scan of iou3d_nms.cpp:116-132 applied to them
+  box_coder.npz    (code, points) -> boxes9 from the reference's PointBinResidual6DCoder.decode_torch
+                   (core/pcdet/utils/box_coder_utils.py imported standalone)
+  det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
+                   PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
+                   built from tests' tiny config with seeded weights, run on seeded scenes.  Its
+                   five extension modules are not buildable here (CUDA), so — as SURVEY.md 8c / A.5
+                   describe — they are replaced by the CPU oracle's ops; missing third-party
+                   imports irrelevant to the path (easydict, numba, spconv, SharedArray, skimage)
+                   are stubbed.  The fixture pins every piece of glue arithmetic and data flow
+                   around the ops; the index ops themselves stay unpinned at the reference level.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/core"
+
+from oracle import ops as oops  # noqa: E402
+from oracle import ref as oref  # noqa: E402
+from tests.util import make_batch, random_boxes  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- NMS fixtures
+def gen_nms():
+    out = {}
+    cases = [(1, 30.0), (2, 3.0), (63, 12.0), (64, 12.0), (65, 12.0), (256, 25.0), (512, 40.0)]
+    for k, spread in cases:
+        boxes = random_boxes(100 + k, k, spread=spread)
+        if k >= 8:
+            boxes[3] = boxes[1]                    # identical boxes
+            boxes[5, 3:5] = 0.0                    # zero-area box
+            boxes[6] = boxes[2]; boxes[6, 0] += boxes[2, 3]  # touching, same heading
+            boxes[7, 6] = 0.0; boxes[7 - 1, 6] = np.pi / 2   # axis aligned / right angle
+        iou = oref.boxes_iou_bev_cpu(boxes, boxes)
+        out["boxes_%d" % k] = boxes
+        out["iou_%d" % k] = iou
+        for thr in (0.01, 0.1, 0.7):
+            out["keep_%d_%s" % (k, str(thr).replace('.', 'p'))] = oops.nms_from_iou(iou, thr)
+    np.savez_compressed(os.path.join(HERE, "nms_ref.npz"), **out)
+    print("nms_ref.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------- box coder
+def gen_box_coder():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_box_coder_utils", os.path.join(REF, "pcdet/utils/box_coder_utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(7)
+    out = {}
+    for name, kw in (("ga", dict(ground_aware=True, minus=False)), ("ga_minus", dict(ground_aware=True, minus=True)),
+                     ("plain", dict(ground_aware=False))):
+        coder = mod.PointBinResidual6DCoder(use_mean_size=False, angle_bin_num=12, threshold=10, factor=45, **kw)
+        code = (rng.normal(size=(400, coder.code_size)) * 1.5).astype(np.float32)
+        code[:10, 6:18] = 0.0  # all-equal yaw logits -> argmax 0
+        pts = (rng.normal(size=(400, 3)) * 20).astype(np.float32)
+        boxes = coder.decode_torch(torch.from_numpy(code), torch.from_numpy(pts)).numpy()
+        out["code_" + name], out["pts_" + name], out["boxes_" + name] = code, pts, boxes
+    np.savez_compressed(os.path.join(HERE, "box_coder.npz"), **out)
+    print("box_coder.npz")
+
+
+# ----------------------------------------------------------------------------- whole model
+def install_reference_stubs():
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            elif isinstance(v, (list, tuple)):
+                v = type(v)(EasyDict(x) if isinstance(x, dict) and not isinstance(x, EasyDict) else x for x in v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("SharedArray")
+    mod("easydict", EasyDict=EasyDict)
+    ident = lambda *a, **k: (a[0] if a and callable(a[0]) and not k else (lambda f: f))  # noqa: E731
+    cuda = mod("numba.cuda", jit=ident)
+    mod("numba", jit=ident, cuda=cuda, njit=ident, prange=range)
+    mod("skimage"); mod("skimage.io"); mod("skimage.transform")
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            return type(k, (), {})
+    sys.modules["spconv"] = _Any("spconv")
+    sys.modules["spconv.pytorch"] = _Any("spconv.pytorch")
+    sys.modules["spconv"].__dict__["pytorch"] = sys.modules["spconv.pytorch"]
+    mod("pcdet.version", __version__="ref")
+
+    # ---- the five extension modules: CPU oracle ops behind the reference's pybind signatures ----
+    def T(a):
+        return a.detach().cpu().numpy()
+
+    def fps(b, n, m, xyz, temp, idx):
+        idx.copy_(torch.from_numpy(oops.fps(T(xyz), m))); return 1
+
+    def fpsw(b, n, m, xyz, w, temp, idx):
+        idx.copy_(torch.from_numpy(oops.fps_weights(T(xyz), T(w), m))); return 1
+
+    def gather(b, c, n, npoints, points, idx, out):
+        out.copy_(torch.from_numpy(oops.gather_points(T(points), T(idx)))); return 1
+
+    def bq(b, n, m, radius, ns, new_xyz, xyz, idx):
+        idx.copy_(torch.from_numpy(oops.ball_query(radius, ns, T(xyz), T(new_xyz)))); return 1
+
+    def bqc(b, n, m, radius, ns, new_xyz, xyz, cnt, idx):
+        c, i = oops.ball_query_cnt(radius, ns, T(xyz), T(new_xyz))
+        cnt.copy_(torch.from_numpy(c)); idx.copy_(torch.from_numpy(i)); return 1
+
+    def bqd(b, n, m, rin, rout, ns, new_xyz, xyz, cnt, idx):
+        c, i = oops.ball_query_dilated(rin, rout, ns, T(xyz), T(new_xyz))
+        cnt.copy_(torch.from_numpy(c)); idx.copy_(torch.from_numpy(i)); return 1
+
+    def group(b, c, n, npoints, ns, points, idx, out):
+        out.copy_(torch.from_numpy(oops.group_points(T(points), T(idx)))); return 1
+
+    def three_nn(b, n, m, unknown, known, d2, idx):
+        d, i = oops.three_nn(T(unknown), T(known))
+        d2.copy_(torch.from_numpy(d)); idx.copy_(torch.from_numpy(i))
+
+    def three_interp(b, c, m, n, points, idx, w, out):
+        out.copy_(torch.from_numpy(oops.three_interpolate(T(points), T(idx), T(w))))
+
+    mod("pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda",
+        farthest_point_sampling_wrapper=fps, furthest_point_sampling_weights_wrapper=fpsw,
+        gather_points_wrapper=gather, ball_query_wrapper=bq, ball_query_cnt_wrapper=bqc,
+        ball_query_dilated_wrapper=bqd, group_points_wrapper=group, three_nn_wrapper=three_nn,
+        three_interpolate_wrapper=three_interp)
+    mod("pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda")
+
+    def nms_gpu(boxes, keep, thr):
+        k = oops.nms(T(boxes), thr)
+        keep[:len(k)] = torch.from_numpy(k); return len(k)
+
+    def overlap(a, b, out):
+        out.copy_(torch.from_numpy(oops.boxes_overlap_bev(T(a), T(b)))); return 1
+
+    def ioubev(a, b, out):
+        out.copy_(torch.from_numpy(oops.boxes_iou_bev(T(a), T(b)))); return 1
+
+    mod("pcdet.ops.iou3d_nms.iou3d_nms_cuda", nms_gpu=nms_gpu, boxes_overlap_bev_gpu=overlap,
+        boxes_iou_bev_gpu=ioubev, boxes_iou_bev_cpu=ioubev)
+    mod("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda")
+    mod("pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda")
+
+    torch.cuda.IntTensor = torch.IntTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    return EasyDict
+
+
+def gen_model():
+    import yaml
+    EasyDict = install_reference_stubs()
+    sys.path.insert(0, REF)
+    import pcdet.models as ref_models  # the REFERENCE's package (REF is first on sys.path)
+    assert ref_models.__file__.startswith(REF)
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "de6d_amd/cfgs/synthetic_models/det6d_tiny.yaml")))
+    # weights come from OUR builder (same parameter names/shapes; checked below) so that the test
+    # can rebuild them from the seed instead of shipping a checkpoint
+    from de6d_amd.runtime import load_config, build_model
+    ours = build_model(load_config('synthetic_models/det6d_tiny.yaml'), seed=2024)
+    sd = ours.state_dict()
+
+    class DS(object):
+        class_names = cfg['CLASS_NAMES']
+        point_feature_encoder = EasyDict(num_point_features=4)
+        grid_size = None
+        voxel_size = None
+        point_cloud_range = np.array(cfg['DATA_CONFIG']['POINT_CLOUD_RANGE'], np.float32)
+        depth_downsample_factor = None
+
+    ref = ref_models.build_network(EasyDict(cfg['MODEL']), num_class=1, dataset=DS())
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "state-dict key order differs from the reference"
+    for k in sd:
+        assert ref_sd[k].shape == sd[k].shape, k
+    ref.load_state_dict(sd)
+    ref.eval()
+
+    b, n, seed = 2, 2048, 300
+    batch = make_batch(seed, b, n, tilt=True)
+    pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
+    bd = {'batch_size': b, 'points': torch.from_numpy(pts)}
+    with torch.no_grad():
+        pred, _ = ref(bd)
+    out = dict(seed=np.int64(2024), scene_seed=np.int64(seed), b=np.int64(b), n=np.int64(n),
+               n_state=np.int64(len(sd)), n_params=np.int64(sum(p.numel() for p in ref.parameters())))
+    for i, t in enumerate(bd['point_coords_list']):
+        out['point_coords_list_%d' % i] = t.numpy()
+    for i, t in enumerate(bd['point_scores_list']):
+        if t is not None:
+            out['point_scores_list_%d' % i] = t.numpy()
+    for key in ('point_features', 'point_coords', 'point_candidate_coords', 'point_vote_coords', 'batch_index',
+                'batch_cls_preds', 'batch_box_preds', 'point_reg_preds', 'point_cls_scores', 'vote_offsets'):
+        out[key] = bd[key].numpy()
+    for i, p in enumerate(pred):
+        out['pred_boxes_%d' % i] = p['pred_boxes'].numpy()
+        out['pred_scores_%d' % i] = p['pred_scores'].numpy()
+        out['pred_labels_%d' % i] = p['pred_labels'].numpy()
+    np.savez_compressed(os.path.join(HERE, "det6d_tiny.npz"), **out)
+    print("det6d_tiny.npz: %d detections" % sum(len(p['pred_scores']) for p in pred))
+
+    # full-size construction facts: parameter count and key list of the reference
+    full = yaml.safe_load(open(os.path.join(ROOT, "de6d_amd/cfgs/kitti_models/det6d_car.yaml")))
+    ref_full = ref_models.build_network(EasyDict(full['MODEL']), num_class=1, dataset=DS())
+    keys = list(ref_full.state_dict().keys())
+    shapes = [list(v.shape) for v in ref_full.state_dict().values()]
+    import json
+    json.dump({"keys": keys, "shapes": shapes, "n_params": int(sum(p.numel() for p in ref_full.parameters()))},
+              open(os.path.join(HERE, "det6d_car_state_dict.json"), "w"))
+    print("det6d_car_state_dict.json", len(keys), "entries")
+
+
+if __name__ == "__main__":
+    oops.build()
+    assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
+    gen_nms()
+    gen_box_coder()
+    gen_model()

@@ -1,0 +1,87 @@
+"""The drop-in boundary without a GPU: the C-ABI library builds, loads, and exports every symbol
+include/det6d_ops.h declares; the product never touches the oracle; missing pieces fail loudly."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    from de6d_amd import _build
+    return _build.build()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'det6d_ops.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(det6d_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    import torch  # noqa: F401  (loads libamdhip64 first, like the product does)
+    lib = ctypes.CDLL(hip_lib)
+    names = declared_symbols()
+    assert len(names) >= 27
+    for name in names:
+        assert hasattr(lib, name), "libdet6d_hip.so does not export %s" % name
+    from de6d_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    lib.det6d_version.restype = ctypes.c_char_p
+    assert lib.det6d_version().startswith(b"det6d-hip gfx950")
+
+
+def test_code_object_is_gfx950_only(hip_lib):
+    out = subprocess.run(['strings', hip_lib], capture_output=True, text=True).stdout
+    assert 'gfx950' in out
+    assert 'gfx90a' not in out and 'gfx942' not in out and 'sm_' not in out
+
+
+def test_oracle_exports_mirror_the_abi(oracle_ops):
+    lib = oracle_ops.lib()
+    for name in declared_symbols():
+        if name in ('det6d_version', 'det6d_last_error', 'det6d_nms_to_host'):
+            continue
+        assert hasattr(lib, name.replace('det6d_', 'det6d_oracle_', 1)), name
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'de6d_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M) or 'libdet6d_oracle' in src:
+                    bad.append(os.path.join(base, f))
+    assert not bad, "product files reference the oracle: %s" % bad
+
+
+def test_ops_fail_loudly_without_device_tensors(hip_lib):
+    import torch
+    from de6d_amd._lib import Det6dError
+    from de6d_amd.ops import pointnet2_batch_hip as pn
+    xyz = torch.zeros((1, 8, 3))
+    with pytest.raises(Det6dError):
+        pn.farthest_point_sampling_wrapper(1, 8, 4, xyz, torch.zeros((1, 8)), torch.zeros((1, 4), dtype=torch.int32))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from de6d_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.Det6dError):
+        _lib.lib()
+
+
+def test_invalid_arguments_return_status_not_exit(hip_lib):
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(hip_lib)
+    assert lib.det6d_fps(1, 0, 4, None, None, None, None) == -1          # DET6D_EINVAL
+    assert lib.det6d_ball_query(1, 8, 4, ctypes.c_float(1.0), 1000, None, None, None, None) == -1
+    assert lib.det6d_linear(None, None) == -1
+    assert lib.det6d_fps(0, 8, 4, ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), None) == 0  # b = 0: nothing to do

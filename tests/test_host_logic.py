@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference API (no GPU): config, registries, state-dict layout,
+BN folding, workload accounting."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_yaml_and_overrides(tmp_path):
+    from de6d_amd.pcdet.config import EasyDict, cfg_from_list, cfg_from_yaml_file, merge_new_config
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, 'de6d_amd/cfgs/kitti_models/det6d_car.yaml'), EasyDict())
+    assert cfg.MODEL.NAME == 'Det6D' and cfg.MODEL.BACKBONE_3D.SA_CONFIG.NPOINT_LIST[1] == [512, 512]
+    assert cfg.DATA_CONFIG.DATA_PROCESSOR[1].NUM_POINTS.test == 16384
+    assert cfg.MODEL.POINT_HEAD.get('NOT_THERE', 7) == 7
+    cfg_from_list(['MODEL.POST_PROCESSING.SCORE_THRESH', '0.3', 'MODEL.POST_PROCESSING.NMS_CONFIG.NMS_TYPE', 'nms_gpu',
+                   'MODEL.POINT_HEAD.SAMPLE_RANGE', '0,128'], cfg)
+    assert cfg.MODEL.POST_PROCESSING.SCORE_THRESH == 0.3 and cfg.MODEL.POINT_HEAD.SAMPLE_RANGE == [0, 128]
+    with pytest.raises(AssertionError):
+        cfg_from_list(['MODEL.NO_SUCH_KEY', '1'], cfg)
+    base = tmp_path / 'base.yaml'
+    base.write_text("A: {x: 1, y: 2}\nB: 3\n")
+    child = tmp_path / 'child.yaml'
+    child.write_text("_BASE_CONFIG_: %s\nA: {y: 5}\n" % base)
+    merged = cfg_from_yaml_file(str(child), EasyDict())
+    assert merged.A.x == 1 and merged.A.y == 5 and merged.B == 3
+    assert merge_new_config(EasyDict(), {'K': {'z': [1, {'q': 2}]}}).K.z[1].q == 2
+
+
+def test_state_dict_layout_equals_the_reference():
+    """key names, order and shapes recorded from the reference's own build_network
+    (tests/golden/det6d_car_state_dict.json) -> reference checkpoints load unchanged"""
+    from de6d_amd.runtime import load_config, build_model
+    ref = json.load(open(os.path.join(ROOT, 'tests/golden/det6d_car_state_dict.json')))
+    model = build_model(load_config('kitti_models/det6d_car.yaml'))
+    sd = model.state_dict()
+    assert list(sd.keys()) == ref['keys']
+    assert [list(v.shape) for v in sd.values()] == ref['shapes']
+    assert sum(p.numel() for p in model.parameters()) == ref['n_params'] == 2356422
+
+
+def test_registries_and_checkpoint_roundtrip(tmp_path):
+    from de6d_amd.pcdet.models import backbones_3d, dense_heads, detectors
+    from de6d_amd.runtime import load_config, build_model
+    assert 'PointNet2FSMSG' in backbones_3d.__all__ and 'PointHeadBox6DVote' in dense_heads.__all__
+    assert 'Det6D' in detectors.__all__
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    a = build_model(cfg, seed=1)
+    path = tmp_path / 'checkpoint_epoch_80.pth'
+    torch.save({'epoch': 80, 'it': 1, 'model_state': a.state_dict(), 'version': 'pcdet+0.5.2'}, str(path))
+
+    class Log:
+        def info(self, *_):
+            pass
+    b = build_model(cfg, seed=2)
+    b.load_params_from_file(str(path), Log(), to_cpu=True)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    with pytest.raises(NotImplementedError):
+        bad = load_config('synthetic_models/det6d_tiny.yaml')
+        bad.MODEL['ROI_HEAD'] = {'NAME': 'x'}
+        build_model(bad)
+
+
+def test_bn_folding_matches_torch_eval():
+    from de6d_amd.pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import fold_sequential
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.Conv2d(7, 10, 1, bias=False), torch.nn.BatchNorm2d(10), torch.nn.ReLU(),
+                              torch.nn.Conv2d(10, 5, 1, bias=False), torch.nn.BatchNorm2d(5), torch.nn.ReLU())
+    for m in seq:
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(); m.running_var.uniform_(0.5, 1.5); m.weight.data.normal_(); m.bias.data.normal_()
+    seq.eval()
+    x = torch.randn(3, 7, 11, 4)
+    want = seq(x).permute(0, 2, 3, 1).reshape(-1, 5).detach().numpy()
+    layers = fold_sequential(seq, 8)
+    h = np.zeros((3 * 11 * 4, 8), np.float32)
+    h[:, :7] = x.permute(0, 2, 3, 1).reshape(-1, 7).numpy()
+    for w, s, cout, act in layers:
+        h = h @ w
+        h[:, :cout] += s
+        if act:
+            h = np.maximum(h, 0)
+    np.testing.assert_allclose(h[:, :5], want, rtol=1e-4, atol=1e-5)
+    assert layers[0][0].shape == (8, 12) and layers[1][0].shape == (12, 8)
+
+
+def test_algorithmic_flops_match_survey():
+    from de6d_amd.runtime import load_config, build_model, mlp_flops_per_scene
+    model = build_model(load_config('kitti_models/det6d_car.yaml'))
+    assert abs(mlp_flops_per_scene(model, 16384) / 1e9 - 22.583) < 0.01
+
+
+def test_training_mode_is_refused():
+    from de6d_amd.runtime import load_config, build_model
+    model = build_model(load_config('synthetic_models/det6d_tiny.yaml'))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model({'batch_size': 1, 'points': torch.zeros((2048, 5))})

@@ -1,0 +1,90 @@
+"""Pins the CPU oracle against fixtures generated FROM THE REFERENCE (tests/golden/make_golden.py):
+the reference's own iou3d_cpu.cpp, its PointBinResidual6DCoder, and its Python model glue."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_nms_against_reference_iou3d_cpu(oracle_ops):
+    z = np.load(os.path.join(G, 'nms_ref.npz'))
+    for k in (1, 2, 63, 64, 65, 256, 512):
+        boxes = z['boxes_%d' % k]
+        iou = oracle_ops.boxes_iou_bev(boxes, boxes)
+        # same geometry, our deterministic sin/cos/atan2 instead of glibc: few-ulp differences
+        np.testing.assert_allclose(iou, z['iou_%d' % k], rtol=0, atol=2e-5)
+        for thr in (0.01, 0.1, 0.7):
+            want = z['keep_%d_%s' % (k, str(thr).replace('.', 'p'))]
+            np.testing.assert_array_equal(oracle_ops.nms(boxes, thr), want)
+            np.testing.assert_array_equal(oracle_ops.nms_from_iou(iou, thr), want)
+
+
+def test_nms_mask_layout_matches_greedy(oracle_ops):
+    z = np.load(os.path.join(G, 'nms_ref.npz'))
+    boxes = z['boxes_65']
+    mask = oracle_ops.nms_mask(boxes, 0.1)
+    assert mask.shape == (65, 2)
+    iou = z['iou_65']
+    for i in (0, 10, 63, 64):
+        for j in range(65):
+            bit = (int(mask[i, j // 64]) >> (j % 64)) & 1
+            # diagonal tiles are upper-triangular, off-diagonal tiles are full (iou3d_nms_kernel.cu:293-296)
+            same_block = (i // 64) == (j // 64)
+            want = int(iou[i, j] > 0.1 and (j > i or not same_block))
+            assert bit == want or abs(iou[i, j] - 0.1) < 1e-4
+
+
+@pytest.mark.parametrize("name,kw", [("ga", dict(ground_aware=True, minus=False)),
+                                     ("ga_minus", dict(ground_aware=True, minus=True)),
+                                     ("plain", dict(ground_aware=False))])
+def test_box_decode_against_reference_coder(oracle_ops, name, kw):
+    z = np.load(os.path.join(G, 'box_coder.npz'))
+    got = oracle_ops.decode_boxes(z['code_' + name], z['pts_' + name], nbin=12, **kw)
+    want = z['boxes_' + name]
+    np.testing.assert_array_equal(got[:, :3], want[:, :3])            # x, y, z: one fp32 add
+    np.testing.assert_allclose(got[:, 3:6], want[:, 3:6], rtol=3e-7)  # exp(): <= 2 ulp
+    np.testing.assert_array_equal(got[:, 6], want[:, 6])              # yaw bin + residual
+    np.testing.assert_array_equal(got[:, 7:], want[:, 7:])            # pitch branch, roll
+
+
+def _oracle_tiny():
+    from de6d_amd.runtime import load_config, build_model
+    from oracle import model as omodel
+    from tests.util import make_batch
+    z = np.load(os.path.join(G, 'det6d_tiny.npz'))
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=int(z['seed']))
+    b, n = int(z['b']), int(z['n'])
+    batch = make_batch(int(z['scene_seed']), b, n, tilt=True)
+    pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    assert len(sd) == int(z['n_state'])
+    return z, omodel.forward(cfg.MODEL, sd, pts, b), b
+
+
+def test_whole_model_against_reference_python(oracle_ops):
+    """oracle/model.py vs the reference's own PointNet2FSMSG + PointHeadBox6DVote +
+    post_processing (torch-CPU math).  Sampled point sets must be identical; features / boxes
+    within the north-star tolerance (1e-4 abs)."""
+    z, ref, b = _oracle_tiny()
+    for lvl, xyz in enumerate(ref['l_xyz']):
+        np.testing.assert_array_equal(z['point_coords_list_%d' % lvl][:, 1:], xyz.reshape(-1, 3))
+    for lvl in (0, 1):
+        np.testing.assert_allclose(z['point_scores_list_%d' % lvl].reshape(b, -1), ref['l_scores'][lvl], atol=1e-4)
+    np.testing.assert_allclose(ref['point_features'], z['point_features'], atol=1e-4)
+    np.testing.assert_allclose(ref['point_vote_coords'], z['point_vote_coords'][:, 1:], atol=1e-4)
+    np.testing.assert_allclose(ref['batch_cls_preds'], z['batch_cls_preds'], atol=1e-4)
+    np.testing.assert_allclose(ref['point_reg_preds'], z['point_reg_preds'], atol=1e-4)
+    np.testing.assert_allclose(ref['batch_box_preds'], z['batch_box_preds'], atol=1e-4)
+    for i in range(b):
+        want_b, want_s = z['pred_boxes_%d' % i], z['pred_scores_%d' % i]
+        got = ref['pred_dicts'][i]
+        assert got['pred_boxes'].shape == want_b.shape
+        np.testing.assert_allclose(got['pred_scores'], want_s, atol=1e-5)   # both sorted descending
+        np.testing.assert_array_equal(got['pred_labels'], z['pred_labels_%d' % i])
+        # scores that differ by an ulp between torch-CPU and the fmaf chain may swap neighbours in
+        # the order: match every golden detection to an oracle detection instead of row-by-row
+        d = np.abs(got['pred_boxes'][None, :, :] - want_b[:, None, :]).max(-1)
+        assert (d.min(axis=1) < 1e-4).all() and (d.min(axis=0) < 1e-4).all()
