@@ -16,6 +16,7 @@
 //    starts without a dependent global load;
 //  * LDS slots are double-buffered by round parity: one s_barrier per round.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -157,6 +158,208 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
   }
 }
 
+
+// ---- hand-placed wave64 max reductions: one v_max_f32_dpp per step (hipcc expands the builtin
+// form into mov + mov_dpp + 2 canonicalising max per step).  Inline asm gets no hazard padding
+// from the compiler: a DPP read of a VGPR written by the previous VALU op needs 2 wait states.
+__device__ __forceinline__ float wave_max64_asm(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(t)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+}
+// max over lanes 0..15 (one DPP row); result read from lane 0
+__device__ __forceinline__ float row_max16_asm(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(t)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0));
+}
+__device__ __forceinline__ float vmin_asm(float a, float b) {  // v_min_f32 == fminf, no canonicalise
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// coordinates of slot `ws` (wave-uniform) of lane `wl`: scalar branches down to one slot
+template <int LO, int HI, int N>
+__device__ __forceinline__ void pick_slot(int ws, int wl, const float (&px)[N], const float (&py)[N],
+                                          const float (&pz)[N], float &sx, float &sy, float &sz) {
+  if constexpr (HI - LO == 1) {
+    sx = d6_readlane_f(px[LO], wl);
+    sy = d6_readlane_f(py[LO], wl);
+    sz = d6_readlane_f(pz[LO], wl);
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (ws < MID) pick_slot<LO, MID>(ws, wl, px, py, pz, sx, sy, sz);
+    else pick_slot<MID, HI>(ws, wl, px, py, pz, sx, sy, sz);
+  }
+}
+
+// Fat-thread fast path.  The reference's block has S = opt_n_threads(N) virtual threads; their
+// tie priority is p = bitrev(v).  Here T = 2^LOG2T <= S hardware threads each emulate S/T virtual
+// threads with CONSECUTIVE priorities p = h*S/T .. (h+1)*S/T - 1 and scan their SLOTS = N/T points in
+// (p, j) order, so "lowest hardware thread, then first slot" is still exactly the reference's rule —
+// but the per-round reduction/broadcast code (which every wave executes) runs on 8, 4 or 1 waves
+// instead of 16, and a single-wave block (N <= 1024) needs no LDS and no barrier at all.
+// Distances are evaluated two points at a time with packed fp32 ops (v_pk_add/mul/fma_f32).
+template <int LOG2T, int SLOTS, bool WEIGHTED>
+__global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int log2s, int log2pptv,
+                                                             const float *__restrict__ xyz,
+                                                             const float *__restrict__ weights,
+                                                             float *__restrict__ temp,
+                                                             int *__restrict__ idxs) {
+  static_assert(SLOTS >= 2 && SLOTS % 2 == 0, "pairs");
+  constexpr int T = 1 << LOG2T;
+  constexpr int NW = T / 64;
+  constexpr int H = SLOTS / 2;
+  __shared__ Slot slots[2][NW > 1 ? NW : 1];
+  const int h = threadIdx.x;
+  const int lane = h & 63;
+  const int wave = h >> 6;
+  const int log2vpt = log2s - LOG2T;            // virtual threads per hardware thread
+
+  xyz += (size_t)blockIdx.x * n * 3;
+  temp += (size_t)blockIdx.x * n;
+  idxs += (size_t)blockIdx.x * m;
+  if (WEIGHTED) weights += (size_t)blockIdx.x * n;
+
+  auto slot_point = [&](int s) {  // slot -> point index k = v + S * j
+    const int pl = s >> log2pptv, j = s & ((1 << log2pptv) - 1);
+    const int v = (int)bitrev_n((unsigned)((h << log2vpt) + pl), log2s);
+    return v + (j << log2s);
+  };
+
+  float px[SLOTS], py[SLOTS], pz[SLOTS];   // statically indexed only -> plain VGPRs
+  float pt[SLOTS];
+  double pw[SLOTS];
+  float pwf[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int k = slot_point(s);
+    px[s] = xyz[(size_t)k * 3 + 0];
+    py[s] = xyz[(size_t)k * 3 + 1];
+    pz[s] = xyz[(size_t)k * 3 + 2];
+    // cut the values loose from the dwordx3 load tuple, otherwise the allocator keeps the triple
+    // AND the (x_s, x_s+1) pair copies the packed ops need alive for the whole kernel
+    asm volatile("" : "+v"(px[s]), "+v"(py[s]), "+v"(pz[s]));
+    pt[s] = temp[k];
+    if (WEIGHTED) {
+      pwf[s] = weights[k];
+      pw[s] = fmax((double)pwf[s], 1e-12);   // `max(weights[k], 1e-12)` in double, sampling_gpu.cu:466
+    }
+  }
+
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  int first_round = WEIGHTED ? 0 : 1;
+  if (!WEIGHTED) {
+    if (h == 0) idxs[0] = 0;
+    cx = xyz[0]; cy = xyz[1]; cz = xyz[2];
+  }
+
+  for (int r = first_round; r < m; ++r) {
+    float best = -1.0f;
+    int bs = 0;
+    if (WEIGHTED && r == 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const bool up = pwf[s] > best;
+        bs = up ? s : bs;
+        best = up ? pwf[s] : best;
+      }
+    } else {
+      const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+      for (int q = 0; q < H; ++q) {
+        const f32x2 dx = f32x2{px[2 * q], px[2 * q + 1]} - c2x;
+        const f32x2 dy = f32x2{py[2 * q], py[2 * q + 1]} - c2y;
+        const f32x2 dz = f32x2{pz[2 * q], pz[2 * q + 1]} - c2z;
+        f32x2 d = dy * dy;
+        d = __builtin_elementwise_fma(dx, dx, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int s = 2 * q + e;
+          const float t = vmin_asm(d[e], pt[s]);
+          pt[s] = t;
+          float score = t;
+          if (WEIGHTED) score = (float)((double)t * pw[s]);
+          const bool up = score > best;
+          bs = up ? s : bs;
+          best = up ? score : best;
+        }
+      }
+    }
+    // a thread that found nothing keeps (-1, k = 0) like the reference's (best = -1, besti = 0)
+    const bool found = best > -1.0f;
+
+    const float wmax = wave_max64_asm(best);
+    const unsigned long long tie = __ballot(best == wmax);
+    const int wl = __builtin_ctzll(tie);
+    const int ws = d6_readlane_i(found ? bs : -1, wl);
+    int old;
+    float sx, sy, sz;
+    if (ws >= 0) {
+      old = d6_readlane_i(slot_point(ws), wl);
+      // ws is wave-uniform: a scalar binary search over the slots, then three v_readlane
+      pick_slot<0, SLOTS>(ws, wl, px, py, pz, sx, sy, sz);
+    } else {
+      old = 0;
+      sx = xyz[0]; sy = xyz[1]; sz = xyz[2];
+    }
+    if (NW > 1) {
+      Slot *sl = slots[r & 1];
+      if (lane == 0) {
+        sl[wave].val = wmax;
+        sl[wave].idx = old;
+        sl[wave].x = sx; sl[wave].y = sy; sl[wave].z = sz;
+      }
+      __syncthreads();
+      const int src = lane & (NW - 1);
+      const float v2 = sl[src].val;
+      const int i2 = sl[src].idx;
+      const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
+      const float bmax = row_max16_asm(v2);    // NW <= 16: lanes 0..15 hold every wave's entry
+      const unsigned long long tie2 = __ballot(v2 == bmax);
+      const int ww = __builtin_ctzll(tie2);    // lowest wave among the maxima
+      old = d6_readlane_i(i2, ww);
+      sx = d6_readlane_f(x2, ww);
+      sy = d6_readlane_f(y2, ww);
+      sz = d6_readlane_f(z2, ww);
+    }
+    cx = sx; cy = sy; cz = sz;
+    if (h == 0) idxs[r] = old;
+  }
+  // `temp` is scratch: the reference's callers discard it (pointnet2_utils.py:26-29), so the final
+  // min-distances are not written back here (the generic kernels below still do).
+}
+
 // Generic fallback for N > 16 * 1024: same schedule, min-distances and coordinates stay in
 // memory (L2) like the reference kernel.  Correct for any N; not a tuned path.
 template <bool WEIGHTED>
@@ -238,6 +441,28 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
   const int threads = S < 64 ? 64 : S;
   const int ppt = (n + S - 1) / S;
   dim3 grid(b), block(threads);
+  // fat-thread kernels: N = SLOTS << LOG2T exactly, T <= S
+#define FPS_FAT(LT, SL)                                                                        \
+  do {                                                                                         \
+    int lp = 0;                                                                                \
+    while ((1 << lp) < ppt) ++lp;                                                              \
+    hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), 0, stream, n, m, log2s, \
+                       lp, xyz, weights, temp, idx);                                           \
+    return det6d_check_launch("det6d_fps");                                                    \
+  } while (0)
+  if (n == S * ppt && (ppt & (ppt - 1)) == 0) {
+    // thread counts picked by measurement on MI355X (scripts/gpu_fps_time.py): the scan is bound
+    // by VALU issue (7 instructions per point), the argmax/broadcast chain by latency
+    if (n == 16384) FPS_FAT(9, 32);
+    if (n == 8192) FPS_FAT(9, 16);
+    if (n == 4096) FPS_FAT(9, 8);
+    if (n == 2048) FPS_FAT(7, 16);
+    if (n == 1024) FPS_FAT(6, 16);
+    if (n == 512) FPS_FAT(6, 8);
+    if (n == 256) FPS_FAT(6, 4);
+    if (n == 128) FPS_FAT(6, 2);
+  }
+#undef FPS_FAT
 #define FPS_CASE(P)                                                                          \
   hipLaunchKernelGGL((fps_reg_kernel<P, W>), grid, block, 0, stream, n, m, log2s, xyz, weights, \
                      temp, idx)

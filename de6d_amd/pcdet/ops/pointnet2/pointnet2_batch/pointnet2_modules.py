@@ -113,6 +113,7 @@ class _PointnetSAModuleFSBase(nn.Module):
         self.aggregation_mlp = None
         self.confidence_mlp = None
         self._folded = None
+        self._side_streams = None
 
     # ---- weight preparation -------------------------------------------------------------
     def invalidate(self):
@@ -138,22 +139,42 @@ class _PointnetSAModuleFSBase(nn.Module):
         return self._folded
 
     # ---- sampling -----------------------------------------------------------------------
+    def _sample_one(self, xyz, scores, lo, hi, method, npoint):
+        hi = xyz.shape[1] if hi == -1 else hi
+        xyz_slice = xyz[:, lo:hi, :].contiguous()
+        if method == 'd-fps':
+            idx = pointnet2_utils.furthest_point_sample(xyz_slice, npoint)
+        elif method == 's-fps':
+            assert scores is not None
+            weights = fused.sigmoid_pow(scores[:, lo:hi].contiguous(), self.weight_gamma)
+            idx = pointnet2_utils.furthest_point_sample_weights(xyz_slice, weights, npoint)
+        else:
+            raise NotImplementedError(
+                "sampling method %r is outside the Det6D hot path (SURVEY.md 2.1 #8)" % method)
+        return idx + lo if lo else idx
+
     def _sample(self, xyz, scores):
-        idx_list = []
-        for (lo, hi), method, npoint in zip(self.sample_range_list, self.sample_method_list, self.npoint_list):
-            hi = xyz.shape[1] if hi == -1 else hi
-            xyz_slice = xyz[:, lo:hi, :].contiguous()
-            if method == 'd-fps':
-                idx = pointnet2_utils.furthest_point_sample(xyz_slice, npoint)
-            elif method == 's-fps':
-                assert scores is not None
-                weights = fused.sigmoid_pow(scores[:, lo:hi].contiguous(), self.weight_gamma)
-                idx = pointnet2_utils.furthest_point_sample_weights(xyz_slice, weights, npoint)
-            else:
-                raise NotImplementedError(
-                    "sampling method %r is outside the Det6D hot path (SURVEY.md 2.1 #8)" % method)
-            idx_list.append(idx + lo if lo else idx)
-        return idx_list[0] if len(idx_list) == 1 else torch.cat(idx_list, dim=-1)
+        """fusion sampling (pointnet2_modules.py:376-450).  The samplers of one layer are independent
+        latency chains on one workgroup per scene, so they run concurrently on forked HIP streams
+        (also under hipGraph capture, where the fork/join becomes two parallel branches)."""
+        jobs = list(zip(self.sample_range_list, self.sample_method_list, self.npoint_list))
+        if len(jobs) == 1:
+            (lo, hi), method, npoint = jobs[0]
+            return self._sample_one(xyz, scores, lo, hi, method, npoint)
+        main = torch.cuda.current_stream()
+        if self._side_streams is None or len(self._side_streams) < len(jobs) - 1:
+            self._side_streams = [torch.cuda.Stream() for _ in range(len(jobs) - 1)]
+        out = [None] * len(jobs)
+        for i, ((lo, hi), method, npoint) in enumerate(jobs[1:], start=1):
+            side = self._side_streams[i - 1]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out[i] = self._sample_one(xyz, scores, lo, hi, method, npoint)
+        (lo, hi), method, npoint = jobs[0]
+        out[0] = self._sample_one(xyz, scores, lo, hi, method, npoint)
+        for side in self._side_streams[:len(jobs) - 1]:
+            main.wait_stream(side)
+        return torch.cat(out, dim=-1)
 
     # ---- fast path ----------------------------------------------------------------------
     def forward_rows(self, xyz, rows, scores=None, new_xyz=None):
