@@ -99,33 +99,39 @@ int run_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused per-scene post-processing: one 256-thread workgroup per scene, P <= 512 candidates,
-// suppression matrix kept in LDS (32 KB at P = 512).
+// Per-scene post-processing in three short launches over a caller-provided workspace
+// (P <= 512 candidates per scene):
+//   post_rank_kernel   one workgroup per scene: sigmoid, class max, score filter, stable rank
+//                      sort by counting, gather of the sorted boxes;
+//   post_mask_kernel   one WAVE per (sorted row, 64-column block) of the upper-triangular
+//                      suppression matrix, spread over the whole chip (the 64 x 64 tile loop of the
+//                      stand-alone NMS serialises 64 heavy IoU evaluations per wave);
+//   post_select_kernel one wave per scene: greedy scan over the mask (staged in LDS) + outputs.
 // ------------------------------------------------------------------------------------------
 constexpr int kPostThreads = 256;
 constexpr int kPostMaxP = 512;
+constexpr int kPostCB = kPostMaxP / 64;
 
-__global__ __launch_bounds__(kPostThreads) void postprocess_kernel(
-    int p, int ncls, const float *__restrict__ cls, const float *__restrict__ boxes, float score_thr,
-    int pre_max, int post_max, float nms_thr,
-    float *__restrict__ out_boxes, float *__restrict__ out_scores, int *__restrict__ out_labels,
-    int *__restrict__ out_index, int *__restrict__ out_count) {
+struct PostWs {          // layout of the workspace, per scene
+  int cand;
+  int pad[15];
+  float score[kPostMaxP];
+  int label[kPostMaxP];
+  int order[kPostMaxP];
+  float sorted[kPostMaxP * 8];                 // first 7 = box dims used by NMS
+  unsigned long long mask[kPostMaxP * kPostCB];
+};
+
+__global__ __launch_bounds__(kPostThreads) void post_rank_kernel(int p, int ncls, const float *__restrict__ cls,
+                                                                 const float *__restrict__ boxes, float score_thr,
+                                                                 int pre_max, PostWs *__restrict__ ws_all) {
   __shared__ float s_score[kPostMaxP];
-  __shared__ int s_label[kPostMaxP];
-  __shared__ int s_order[kPostMaxP];
-  __shared__ unsigned long long s_remv[kPostMaxP / 64];
-  __shared__ int s_keep[kPostMaxP];
-  __shared__ int s_cand, s_nkeep;
-  __shared__ unsigned long long mask[kPostMaxP * (kPostMaxP / 64)];
-
-  const int bi = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_cand;
+  const int bi = blockIdx.x, tid = threadIdx.x;
+  PostWs &ws = ws_all[bi];
   cls += (size_t)bi * p * ncls;
   boxes += (size_t)bi * p * 9;
-
   if (tid == 0) s_cand = 0;
-  // 1. sigmoid, max over classes (first max wins), label = argmax + 1
   for (int i = tid; i < p; i += kPostThreads) {
     float best = d6_sigmoidf(cls[(size_t)i * ncls]);
     int bl = 0;
@@ -134,10 +140,10 @@ __global__ __launch_bounds__(kPostThreads) void postprocess_kernel(
       if (s > best) { best = s; bl = c; }
     }
     s_score[i] = best;
-    s_label[i] = bl + 1;
+    ws.score[i] = best;
+    ws.label[i] = bl + 1;
   }
   __syncthreads();
-  // 2. stable descending rank by counting (ties: lower original index first)
   for (int i = tid; i < p; i += kPostThreads) {
     const float si = s_score[i];
     if (si >= score_thr) {
@@ -146,71 +152,81 @@ __global__ __launch_bounds__(kPostThreads) void postprocess_kernel(
         const float sj = s_score[j];
         rank += (sj >= score_thr) && (sj > si || (sj == si && j < i));
       }
-      s_order[rank] = i;
+      ws.order[rank] = i;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) ws.sorted[rank * 8 + c] = boxes[(size_t)i * 9 + c];
       atomicAdd(&s_cand, 1);
     }
   }
   __syncthreads();
-  const int cand = min(s_cand, pre_max);
+  if (tid == 0) ws.cand = min(s_cand, pre_max);
+}
+
+__global__ __launch_bounds__(256) void post_mask_kernel(float nms_thr, PostWs *__restrict__ ws_all) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PostWs &ws = ws_all[blockIdx.z];
+  const int cand = ws.cand;
+  const int i = blockIdx.x * 4 + wave;        // sorted row
+  const int col_start = blockIdx.y;
+  if (i >= cand) return;
+  const int row_start = i >> 6;
+  if (col_start < row_start || col_start * 64 >= cand) return;
+  const int col_size = min(cand - col_start * 64, 64);
+  const int j = col_start * 64 + lane;
+  float bi[7], bj[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    bi[c] = ws.sorted[i * 8 + c];
+    bj[c] = lane < col_size ? ws.sorted[j * 8 + c] : 0.f;
+  }
+  const int start = (row_start == col_start) ? (i & 63) + 1 : 0;
+  bool sup = false;
+  if (lane >= start && lane < col_size) sup = d6_iou_bev(bi, bj) > nms_thr;
+  const unsigned long long word = __ballot(sup);
+  if (lane == 0) ws.mask[i * kPostCB + col_start] = word;
+}
+
+__global__ __launch_bounds__(64) void post_select_kernel(int p, const float *__restrict__ boxes, int post_max,
+                                                         const PostWs *__restrict__ ws_all,
+                                                         float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                         int *__restrict__ out_labels, int *__restrict__ out_index,
+                                                         int *__restrict__ out_count) {
+  __shared__ unsigned long long s_mask[kPostMaxP * kPostCB];
+  __shared__ unsigned long long s_remv[kPostCB];
+  __shared__ int s_keep[kPostMaxP];
+  const int bi = blockIdx.x, lane = threadIdx.x;
+  const PostWs &ws = ws_all[bi];
+  boxes += (size_t)bi * p * 9;
+  const int cand = ws.cand;
   const int col_blocks = (cand + 63) / 64;
-  // 3. suppression matrix over the sorted candidates, one wave per tile
-  const int ntiles = col_blocks * col_blocks;
-  for (int tile = wave; tile < ntiles; tile += kPostThreads / 64) {
-    const int row_start = tile / col_blocks, col_start = tile % col_blocks;
-    if (col_start < row_start) {  // never read by the greedy scan (it starts at the row's own block)
-      continue;
-    }
-    const int row_size = min(cand - row_start * 64, 64);
-    const int col_size = min(cand - col_start * 64, 64);
-    float bj[7];
-    const int j = col_start * 64 + lane;
-    const int srcj = lane < col_size ? s_order[j] : 0;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) bj[c] = lane < col_size ? boxes[(size_t)srcj * 9 + c] : 0.f;
-    for (int t = 0; t < row_size; ++t) {
-      const int i = row_start * 64 + t;
-      const int srci = s_order[i];
-      float bx[7];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) bx[c] = boxes[(size_t)srci * 9 + c];
-      const int start = (row_start == col_start) ? t + 1 : 0;
-      bool sup = false;
-      if (lane >= start && lane < col_size) sup = d6_iou_bev(bx, bj) > nms_thr;
-      const unsigned long long word = __ballot(sup);
-      if (lane == 0) mask[(size_t)i * col_blocks + col_start] = word;
+  // stage the rows' live words (own block onward) in LDS: the scan below is a serial chain
+  for (int t = lane; t < cand * kPostCB; t += 64) {
+    const int i = t / kPostCB, w = t % kPostCB;
+    s_mask[t] = (w >= (i >> 6) && w < col_blocks) ? ws.mask[t] : 0ull;
+  }
+  if (lane < kPostCB) s_remv[lane] = 0ull;
+  __syncthreads();
+  int kept = 0;
+  for (int i = 0; i < cand; ++i) {
+    const int nblock = i >> 6, inblock = i & 63;
+    const unsigned long long cur = s_remv[nblock];
+    if (!((cur >> inblock) & 1ull)) {
+      if (lane == 0) s_keep[kept] = i;
+      ++kept;
+      if (lane >= nblock && lane < col_blocks) s_remv[lane] |= s_mask[i * kPostCB + lane];
+      __syncthreads();
     }
   }
   __syncthreads();
-  // 4. greedy scan by wave 0
-  if (wave == 0) {
-    for (int w = lane; w < col_blocks; w += 64) s_remv[w] = 0ull;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    int kept = 0;
-    for (int i = 0; i < cand; ++i) {
-      const int nblock = i >> 6, inblock = i & 63;
-      const unsigned long long cur = s_remv[nblock];
-      if (!((cur >> inblock) & 1ull)) {
-        if (lane == 0) s_keep[kept] = i;
-        ++kept;
-        for (int w = nblock + lane; w < col_blocks; w += 64) s_remv[w] |= mask[(size_t)i * col_blocks + w];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (lane == 0) s_nkeep = min(kept, post_max);
-  }
-  __syncthreads();
-  // 5. outputs
-  const int nkeep = s_nkeep;
-  if (tid == 0) out_count[bi] = nkeep;
-  for (int i = tid; i < post_max; i += kPostThreads) {
+  const int nkeep = min(kept, post_max);
+  if (lane == 0) out_count[bi] = nkeep;
+  for (int i = lane; i < post_max; i += 64) {
     float *ob = out_boxes + ((size_t)bi * post_max + i) * 9;
     if (i < nkeep) {
-      const int src = s_order[s_keep[i]];
+      const int src = ws.order[s_keep[i]];
       for (int c = 0; c < 9; ++c) ob[c] = boxes[(size_t)src * 9 + c];
-      out_scores[(size_t)bi * post_max + i] = s_score[src];
-      out_labels[(size_t)bi * post_max + i] = s_label[src];
+      out_scores[(size_t)bi * post_max + i] = ws.score[src];
+      out_labels[(size_t)bi * post_max + i] = ws.label[src];
       out_index[(size_t)bi * post_max + i] = src;
     } else {
       for (int c = 0; c < 9; ++c) ob[c] = 0.f;
@@ -282,16 +298,22 @@ DET6D_API int det6d_nms_to_host(int boxes_num, const float *boxes, float thresh,
   return rc == DET6D_OK ? n_keep : rc;
 }
 
+DET6D_API int64_t det6d_postprocess_workspace_bytes(int b) { return (int64_t)sizeof(PostWs) * (b > 0 ? b : 0); }
+
 DET6D_API int det6d_postprocess(int b, int p, int ncls, const float *cls, const float *boxes,
-                                float score_thr, int pre_max, int post_max, float nms_thr,
+                                float score_thr, int pre_max, int post_max, float nms_thr, void *workspace,
                                 float *out_boxes, float *out_scores, int *out_labels, int *out_index,
                                 int *out_count, det6d_stream_t stream) {
   if (b < 0 || p <= 0 || p > kPostMaxP || ncls <= 0 || pre_max <= 0 || post_max <= 0 || !cls || !boxes ||
-      !out_boxes || !out_scores || !out_labels || !out_index || !out_count)
+      !workspace || ((uintptr_t)workspace & 15) || !out_boxes || !out_scores || !out_labels || !out_index || !out_count)
     return DET6D_EINVAL;
   if (b == 0) return DET6D_OK;
-  hipLaunchKernelGGL(postprocess_kernel, dim3(b), dim3(kPostThreads), 0, (hipStream_t)stream, p, ncls, cls,
-                     boxes, score_thr, pre_max, post_max, nms_thr, out_boxes, out_scores,
+  hipStream_t s = (hipStream_t)stream;
+  PostWs *ws = (PostWs *)workspace;
+  hipLaunchKernelGGL(post_rank_kernel, dim3(b), dim3(kPostThreads), 0, s, p, ncls, cls, boxes, score_thr,
+                     pre_max > kPostMaxP ? kPostMaxP : pre_max, ws);
+  hipLaunchKernelGGL(post_mask_kernel, dim3(det6d_divup(p, 4), det6d_divup(p, 64), b), dim3(256), 0, s, nms_thr, ws);
+  hipLaunchKernelGGL(post_select_kernel, dim3(b), dim3(64), 0, s, p, boxes, post_max, ws, out_boxes, out_scores,
                      out_labels, out_index, out_count);
   return det6d_check_launch("det6d_postprocess");
 }

@@ -102,8 +102,9 @@ def postprocess(cls, boxes, b, score_thr, pre_max, post_max, nms_thr):
     ol = torch.empty((b, post_max), dtype=torch.int32, device=dev)
     oi = torch.empty((b, post_max), dtype=torch.int32, device=dev)
     oc = torch.empty((b,), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.lib().det6d_postprocess_workspace_bytes(b)),), dtype=torch.uint8, device=dev)
     L.call("det6d_postprocess", b, p, cls.shape[1], L.ptr(cls), L.ptr(boxes), float(score_thr), pre_max,
-           post_max, float(nms_thr), L.ptr(ob), L.ptr(os_), L.ptr(ol), L.ptr(oi), L.ptr(oc), L.stream_ptr())
+           post_max, float(nms_thr), L.ptr(ws), L.ptr(ob), L.ptr(os_), L.ptr(ol), L.ptr(oi), L.ptr(oc), L.stream_ptr())
     return ob, os_, ol, oi, oc
 
 
@@ -118,3 +119,20 @@ def nms_device(boxes, thresh, normal=False):
     L.call("det6d_nms_normal" if normal else "det6d_nms", k, L.ptr(boxes), float(thresh), L.ptr(mask),
            L.ptr(keep), L.ptr(num), L.stream_ptr())
     return keep, num
+
+
+def ball_query_pair(xyz, new_xyz, shell_a, shell_b):
+    """both radius groups of an SA layer in one sweep; shell = (radius_in, radius_out, nsample).
+    Returns (cnt_a, idx_a, cnt_b, idx_b), all int32, fully written by the kernel."""
+    L.require_cuda(xyz, new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    dev = xyz.device
+    cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
+    cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
+    idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)
+    idx_b = torch.empty((b, m, shell_b[2]), dtype=torch.int32, device=dev)
+    L.call("det6d_ball_query_pair", b, n, m, float(shell_a[0]), float(shell_a[1]), shell_a[2], float(shell_b[0]),
+           float(shell_b[1]), shell_b[2], L.ptr(new_xyz), L.ptr(xyz), L.ptr(cnt_a), L.ptr(idx_a), L.ptr(cnt_b),
+           L.ptr(idx_b), L.stream_ptr())
+    return cnt_a, idx_a, cnt_b, idx_b

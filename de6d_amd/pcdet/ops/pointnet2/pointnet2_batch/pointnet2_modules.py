@@ -197,15 +197,25 @@ class _PointnetSAModuleFSBase(nn.Module):
         if pooled.shape[1] != f['pooled_width']:
             pooled[:, f['pooled_width']:].zero_()
         col = 0
-        former_radius = 0.0
-        for radius, nsample, layers in zip(self.radii, self.nsamples, f['groups']):
-            idx_cnt = torch.zeros((b, m), dtype=torch.int32, device=xyz.device)
-            idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
-            if self.dilated_radius_group:
-                pn2.ball_query_dilated_wrapper(b, n, m, former_radius, radius, nsample, new_xyz, xyz, idx_cnt, idx)
-            else:
-                pn2.ball_query_cnt_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx_cnt, idx)
+        # neighbour search: shells [former, radius) when dilated, plain balls otherwise
+        shells, former_radius = [], 0.0
+        for radius, nsample in zip(self.radii, self.nsamples):
+            shells.append((former_radius if self.dilated_radius_group else 0.0, radius, nsample))
             former_radius = radius
+        if len(shells) == 2:
+            ca, ia, cb, ib = fused.ball_query_pair(xyz, new_xyz, shells[0], shells[1])
+            found = [(ca, ia), (cb, ib)]
+        else:
+            found = []
+            for rin, rout, nsample in shells:
+                idx_cnt = torch.zeros((b, m), dtype=torch.int32, device=xyz.device)
+                idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
+                if self.dilated_radius_group:
+                    pn2.ball_query_dilated_wrapper(b, n, m, rin, rout, nsample, new_xyz, xyz, idx_cnt, idx)
+                else:
+                    pn2.ball_query_cnt_wrapper(b, n, m, rout, nsample, new_xyz, xyz, idx_cnt, idx)
+                found.append((idx_cnt, idx))
+        for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
             x = None
             for li, (w, shift, cout, act) in enumerate(layers):
                 last = li == len(layers) - 1

@@ -77,6 +77,15 @@ int det6d_ball_query_dilated(int b, int n, int m, float radius_in, float radius_
                              const float *new_xyz, const float *xyz, int *idx_cnt, int *idx,
                              det6d_stream_t stream);
 
+/* Fused form of two cnt/dilated queries over the same (new_xyz, xyz): shell A accepts
+ * rin_a^2 <= d2 < rout_a^2 (rin = 0: plain ball), shell B likewise; results are identical to two
+ * separate det6d_ball_query_dilated / _cnt calls on zero-filled idx buffers (empty balls are
+ * written as zeros here, so no memset is needed).  One sweep over the points feeds both groups of an
+ * SA layer (pointnet2_modules.py:462-463 loops the groupers over the same inputs). */
+int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
+                          float rout_b, int ns_b, const float *new_xyz, const float *xyz, int *cnt_a,
+                          int *idx_a, int *cnt_b, int *idx_b, det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ grouping ------------- */
 
 /* Replaces group_points_wrapper (group_points_gpu.cu:53-92).
@@ -213,11 +222,15 @@ int det6d_decode_boxes(int rows, int nbin, int ground_aware, int minus, float th
  *   stable descending sort, top pre_max, rotated NMS (dims 0..6) at nms_thr, first post_max.
  * Outputs (device): out_boxes (B,post_max,9), out_scores (B,post_max), out_labels (B,post_max)
  * i32 1-based, out_index (B,post_max) i32 = index of the kept box inside its scene, out_count (B).
+ * `workspace`: det6d_postprocess_workspace_bytes(B) bytes of 16-byte-aligned device scratch
+ * (scores, order, sorted boxes, suppression matrix), owned by the caller like every other buffer.
  * P <= 512 (suppression matrix lives in LDS). Equal scores are ordered by ascending original index (the reference uses an
  * unstable torch sort there). */
+int64_t det6d_postprocess_workspace_bytes(int b);
 int det6d_postprocess(int b, int p, int ncls, const float *cls, const float *boxes, float score_thr,
-                      int pre_max, int post_max, float nms_thr, float *out_boxes, float *out_scores,
-                      int *out_labels, int *out_index, int *out_count, det6d_stream_t stream);
+                      int pre_max, int post_max, float nms_thr, void *workspace, float *out_boxes,
+                      float *out_scores, int *out_labels, int *out_index, int *out_count,
+                      det6d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -227,6 +227,16 @@ ORACLE_API int det6d_oracle_ball_query_dilated(int b, int n, int m, float radius
   return ball_query_shell(b, n, m, 1, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx);
 }
 
+/* fused two-shell form (see include/det6d_ops.h): literally two reference-style queries */
+ORACLE_API int det6d_oracle_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns_a,
+                                            float rin_b, float rout_b, int ns_b, const float *new_xyz,
+                                            const float *xyz, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b) {
+  memset(idx_a, 0, sizeof(int) * (size_t)b * m * ns_a);
+  memset(idx_b, 0, sizeof(int) * (size_t)b * m * ns_b);
+  ball_query_shell(b, n, m, 1, rin_a, rout_a, ns_a, new_xyz, xyz, cnt_a, idx_a);
+  return ball_query_shell(b, n, m, 1, rin_b, rout_b, ns_b, new_xyz, xyz, cnt_b, idx_b);
+}
+
 /* group_points_gpu.cu:53-72 group_points_kernel_fast */
 ORACLE_API int det6d_oracle_group_points(int b, int c, int n, int npoints, int nsample,
                                          const float *points, const int *idx, float *out) {
@@ -632,6 +642,8 @@ ORACLE_API int det6d_oracle_postprocess(int b, int p, int ncls, const float *cls
   free(score); free(label); free(order); free(sorted); free(mask); free(keep);
   return 0;
 }
+
+ORACLE_API int64_t det6d_oracle_postprocess_workspace_bytes(int b) { (void)b; return 0; }
 
 /* math probes for tests/test_math.py */
 ORACLE_API void det6d_oracle_math(int fn, int count, const float *x, const float *y, float *out) {

@@ -247,3 +247,21 @@ def test_postprocess_bit_exact(ext, oracle_ops, p, ncls):
     for g, r in zip(got, ref):
         np.testing.assert_array_equal(g.cpu().numpy(), r)
     assert ref[4][1] == 0 and ref[4][0] > 0
+
+
+@pytest.mark.parametrize("n,m,sa,sb", [(16384, 700, (0.0, 0.2, 16), (0.2, 0.8, 32)), (4096, 1024, (0.0, 0.8, 16), (0.8, 1.6, 32)),
+                                       (512, 256, (0.0, 4.8, 16), (0.0, 6.4, 32)), (100, 7, (0.0, 0.01, 8), (0.0, 50.0, 128)),
+                                       (1000, 33, (1.0, 3.0, 5), (0.5, 2.0, 70))])
+def test_ball_query_pair_matches_two_queries(ext, oracle_ops, n, m, sa, sb):
+    fused = ext[2]
+    b = 2
+    xyz = make_batch(50, b, n, dup_frac=0.05)[..., :3]
+    new_xyz = np.ascontiguousarray(xyz[:, :m] + np.float32(0.01))
+    new_xyz[:, 0] = 1000.0
+    ca, ia, cb, ib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb)
+    oca, oia = oracle_ops.ball_query_dilated(sa[0], sa[1], sa[2], xyz, new_xyz)
+    ocb, oib = oracle_ops.ball_query_dilated(sb[0], sb[1], sb[2], xyz, new_xyz)
+    np.testing.assert_array_equal(ca.cpu().numpy(), oca)
+    np.testing.assert_array_equal(ia.cpu().numpy(), oia)
+    np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
+    np.testing.assert_array_equal(ib.cpu().numpy(), oib)
