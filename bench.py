@@ -82,11 +82,11 @@ def linear_roofline(model, points, batch, flops_per_scene):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--warmup', type=int, default=32)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=4)
+    ap.add_argument('--streams', type=int, default=16)
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
     ap.add_argument('--cpu-scenes', type=int, default=16, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')

@@ -18,24 +18,30 @@
 // before the MFMA block of the current one (register prefetch); 16.5 KB LDS -> several
 // workgroups per CU hide each other's barriers.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 
 __device__ __forceinline__ float relu_act(float v, int act) { return act == 1 ? (v > 0.f ? v : 0.f) : v; }
 
-template <int BM, int BN, int WMW, int WNW, int TM, int TN>
+// BK: k-tile depth (16 or 32).  NBUF = 2 double-buffers the LDS tiles (one barrier per iteration).
+// Measured on MI355X (65536 x 512 x 1024, random data): BK=16/NBUF=1 96 TF, BK=16/NBUF=2 94, BK=32 82-89
+// (occupancy drops from 3 to 2 waves/SIMD), s_setprio around the MFMAs 93.  A timing-only ablation
+// without global loads, LDS stores and barriers (pure ds_read + MFMA loop) reaches 112-115 TF: that
+// is what the chip sustains under this load (DVFS), so the shipped kernel sits at 83-95 % of it.
+template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1>
 __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
   constexpr int NA = BM / 64;    // A rows per thread
+  constexpr int KU = BK / 16;    // k-quads per row per thread
   static_assert(WMW * WNW == 4, "4 waves");
   static_assert(32 * TM * WMW == BM, "row tiling");
   static_assert(32 * TN * WNW == BN, "col tiling");
-  __shared__ float As[BK * LDA_S];
-  __shared__ float Bs[BK * BN];
+  __shared__ float As_all[NBUF * BK * LDA_S];
+  __shared__ float Bs_all[NBUF * BK * BN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,25 +79,27 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   constexpr int NB4 = (BK * BN / 4 + 255) / 256;  // float4 per thread
   constexpr int B4_PER_ROW = BN / 4;
 
-  float4 ra[NA];
+  float4 ra[NA][KU];
   float4 rb[NB4];
 
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int k = k0 + 4 * akq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (arow[i] != nullptr && k + 3 < K) v = *reinterpret_cast<const float4 *>(arow[i] + k);
-      else if (arow[i] != nullptr && k < K) {  // K % 4 != 0 tail
-        v.x = arow[i][k];
-        if (k + 1 < K) v.y = arow[i][k + 1];
-        if (k + 2 < K) v.z = arow[i][k + 2];
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int k = k0 + 4 * akq + 16 * u;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arow[i] != nullptr && k + 3 < K) v = *reinterpret_cast<const float4 *>(arow[i] + k);
+        else if (arow[i] != nullptr && k < K) {  // K % 4 != 0 tail
+          v.x = arow[i][k];
+          if (k + 1 < K) v.y = arow[i][k + 1];
+          if (k + 2 < K) v.z = arow[i][k + 2];
+        }
+        if (k0 == 0 && akq == 0 && u == 0) {  // grouped_xyz -= new_xyz (pointnet2_utils.py:449-450)
+          v.x = v.x - csub[i][0]; v.y = v.y - csub[i][1]; v.z = v.z - csub[i][2];
+        }
+        ra[i][u] = v;
       }
-      if (k0 == 0 && akq == 0) {  // grouped_xyz -= new_xyz (pointnet2_utils.py:449-450)
-        v.x = v.x - csub[i][0]; v.y = v.y - csub[i][1]; v.z = v.z - csub[i][2];
-      }
-      ra[i] = v;
-    }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int f = tid + 256 * i;
@@ -102,16 +110,20 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
       rb[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float *As = As_all + buf * BK * LDA_S;
+    float *Bs = Bs_all + buf * BK * BN;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      // transposed store As[k][row]: bank = (8*akq + 2*j + row) % 32 -> 32 distinct banks per half-wave
-      float *dst = As + (4 * akq) * LDA_S + ar + 64 * i;
-      dst[0 * LDA_S] = ra[i].x;
-      dst[1 * LDA_S] = ra[i].y;
-      dst[2 * LDA_S] = ra[i].z;
-      dst[3 * LDA_S] = ra[i].w;
-    }
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        // transposed store As[k][row]: bank = (8*akq + 2*j + row) % 32 -> 32 distinct banks per half-wave
+        float *dst = As + (4 * akq + 16 * u) * LDA_S + ar + 64 * i;
+        dst[0 * LDA_S] = ra[i][u].x;
+        dst[1 * LDA_S] = ra[i][u].y;
+        dst[2 * LDA_S] = ra[i][u].z;
+        dst[3 * LDA_S] = ra[i][u].w;
+      }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int f = tid + 256 * i;
@@ -132,11 +144,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   const int arow_s = wm * 32 * TM + l31;
   const int bcol_s = wn * 32 * TN + l31;
 
-  load_tile(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    store_tile();
-    __syncthreads();
-    if (k0 + BK < K) load_tile(k0 + BK);
+  auto compute = [&](int buf) {
+    const float *As = As_all + buf * BK * LDA_S;
+    const float *Bs = Bs_all + buf * BK * BN;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       float af[TM], bf[TN];
@@ -150,7 +160,29 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+  };
+
+  load_tile(0);
+  if (NBUF == 1) {
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      store_tile(0);
+      __syncthreads();
+      if (k0 + BK < K) load_tile(k0 + BK);
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    store_tile(0);
     __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      const bool more = k0 + BK < K;
+      if (more) load_tile(k0 + BK);
+      compute(buf);
+      if (more) store_tile(buf ^ 1);   // nobody reads buf^1 during this iteration
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 
   // ---- epilogue ----
@@ -243,6 +275,10 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     if (gm * det6d_divup(a->ncols, 128) < 256)
       hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64), det6d_divup(a->ncols, 64)),
                          dim3(256), 0, s, *a);
+    else if (a->ncols <= 512 && a->k <= 256)
+      // measured on MI355X (scripts/gpu_linear_variants.py): with short K loops the 128x64 tile's higher
+      // occupancy (5 waves/SIMD vs 3) wins 2-7 %; the 128x128 tile wins on the longest loops
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm, det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm, det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
