@@ -71,8 +71,16 @@ def linear_roofline(model, points, batch, flops_per_scene):
     issued = sum(2.0 * r * k * n for _, _, r, k, n in ev)
     alg = flops_per_scene * batch
     achieved = alg / (total_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')))
+    if pmc:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        try:
+            traffic = round(json.load(open(pmc[-1]))['_derived']['linear_kernel']['hbm_bytes_per_launch'])
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": os.path.basename(pmc[-1]) if pmc and traffic else None,
             "kernel": "linear_kernel<BN,...> (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
             "launches_per_step": len(ev), "avg_launch_us": round(total_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_step": round(alg / 1e9, 2), "issued_gflop_per_step": round(issued / 1e9, 2),
