@@ -48,8 +48,21 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   const int wave = tid >> 6;
   const int wm = wave / WNW, wn = wave % WNW;
   const int R = g.rows, K = g.k, N = g.ncols;
-  const int row0 = blockIdx.x * BM;
-  const int colb = blockIdx.y * BN;
+  // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs, each with its
+  // own L2.  All column tiles of a row tile get consecutive slots on ONE XCD, so the A rows they share
+  // are fetched into that L2 once instead of once per column tile (speed only, never correctness).
+  const int gm = (R + BM - 1) / BM, gn = (N + BN - 1) / BN;
+  int row_tile, col_tile;
+  if (gn > 1 && (gm & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    row_tile = (slot / gn) * 8 + xcd;
+    col_tile = slot % gn;
+  } else {
+    row_tile = blockIdx.x / gn;
+    col_tile = blockIdx.x % gn;
+  }
+  const int row0 = row_tile * BM;
+  const int colb = col_tile * BN;
 
   // ---- A loader: each thread owns rows (tid/4) [and (tid/4 + 64)], k-quad (tid%4) of the tile ----
   const int ar = tid >> 2, akq = tid & 3;
@@ -273,21 +286,21 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
     // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles
     if (gm * det6d_divup(a->ncols, 128) < 256)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64), det6d_divup(a->ncols, 64)),
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                          dim3(256), 0, s, *a);
     else if (a->ncols <= 512 && a->k <= 256)
       // measured on MI355X (scripts/gpu_linear_variants.py): with short K loops the 128x64 tile's higher
       // occupancy (5 waves/SIMD vs 3) wins 2-7 %; the 128x128 tile wins on the longest loops
-      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm, det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
     else
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm, det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
     if (gm < 128)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64), 1), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else
-      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm), dim3(256), 0, s, *a);
   } else {
-    hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1>), dim3(gm, 1), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1>), dim3(gm), dim3(256), 0, s, *a);
   }
   return det6d_check_launch("det6d_linear");
 }
