@@ -26,6 +26,18 @@ __device__ __forceinline__ unsigned bitrev_n(unsigned v, int bits) {
   return bits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));
 }
 
+// Strided batch view + fused pre/post steps (used by det6d_fps_fused; the reference-shaped entry
+// points pass the dense defaults): per-scene strides in elements, an index offset added on output
+// (sample ranges, pointnet2_modules.py:380,448-450), implicit 1e10 min-distance initialisation, and
+// s-fps weights computed on the fly as sigmoid(score)**gamma (pointnet2_modules.py:415-419).
+struct FpsView {
+  long long xyz_bstride, w_bstride, temp_bstride, idx_bstride;
+  int idx_add;
+  int init_temp;
+  int w_is_score;
+  float gamma;
+};
+
 struct Slot {
   float val;
   int idx;
@@ -39,7 +51,7 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
                                                        const float *__restrict__ xyz,
                                                        const float *__restrict__ weights,
                                                        float *__restrict__ temp,
-                                                       int *__restrict__ idxs) {
+                                                       int *__restrict__ idxs, const FpsView vw) {
   typedef float vecf __attribute__((ext_vector_type(PPT)));
   __shared__ Slot slots[2][16];
 
@@ -51,10 +63,10 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
   const bool live = h < S;
   const int v = (int)bitrev_n((unsigned)h, log2s);
 
-  xyz += (size_t)blockIdx.x * n * 3;
-  temp += (size_t)blockIdx.x * n;
-  idxs += (size_t)blockIdx.x * m;
-  if (WEIGHTED) weights += (size_t)blockIdx.x * n;
+  xyz += (size_t)blockIdx.x * vw.xyz_bstride;
+  if (temp) temp += (size_t)blockIdx.x * vw.temp_bstride;
+  idxs += (size_t)blockIdx.x * vw.idx_bstride;
+  if (WEIGHTED) weights += (size_t)blockIdx.x * vw.w_bstride;
 
   vecf px, py, pz, pt;
   double pw[PPT];
@@ -66,9 +78,10 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
     px[j] = ok ? xyz[(size_t)k * 3 + 0] : 0.f;
     py[j] = ok ? xyz[(size_t)k * 3 + 1] : 0.f;
     pz[j] = ok ? xyz[(size_t)k * 3 + 2] : 0.f;
-    pt[j] = ok ? temp[k] : 0.f;
+    pt[j] = ok ? (vw.init_temp ? 1e10f : temp[k]) : 0.f;
     if (WEIGHTED) {
       pwf[j] = ok ? weights[k] : 0.f;
+      if (vw.w_is_score) pwf[j] = d6_sigmoid_powf(pwf[j], vw.gamma);
       // max(weights[k], 1e-12) with a double literal (sampling_gpu.cu:466); fmax drops a NaN weight
       pw[j] = fmax((double)pwf[j], 1e-12);
     }
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
     first_round = 0;
   } else {
     first_round = 1;
-    if (h == 0) idxs[0] = 0;
+    if (h == 0) idxs[0] = vw.idx_add;
     cx = xyz[0]; cy = xyz[1]; cz = xyz[2];
   }
 
@@ -147,14 +160,14 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
     cx = d6_readlane_f(x2, ww);
     cy = d6_readlane_f(y2, ww);
     cz = d6_readlane_f(z2, ww);
-    if (h == 0) idxs[r] = old;
+    if (h == 0) idxs[r] = old + vw.idx_add;
   }
 
   // leave the final min-distances in temp like the reference does
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int k = v + (j << log2s);
-    if (live && k < n) temp[k] = pt[j];
+    if (live && k < n && temp) temp[k] = pt[j];
   }
 }
 
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
                                                              const float *__restrict__ xyz,
                                                              const float *__restrict__ weights,
                                                              float *__restrict__ temp,
-                                                             int *__restrict__ idxs) {
+                                                             int *__restrict__ idxs, const FpsView vw) {
   static_assert(SLOTS >= 2 && SLOTS % 2 == 0, "pairs");
   constexpr int T = 1 << LOG2T;
   constexpr int NW = T / 64;
@@ -245,10 +258,10 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
   const int wave = h >> 6;
   const int log2vpt = log2s - LOG2T;            // virtual threads per hardware thread
 
-  xyz += (size_t)blockIdx.x * n * 3;
-  temp += (size_t)blockIdx.x * n;
-  idxs += (size_t)blockIdx.x * m;
-  if (WEIGHTED) weights += (size_t)blockIdx.x * n;
+  xyz += (size_t)blockIdx.x * vw.xyz_bstride;
+  if (temp) temp += (size_t)blockIdx.x * vw.temp_bstride;
+  idxs += (size_t)blockIdx.x * vw.idx_bstride;
+  if (WEIGHTED) weights += (size_t)blockIdx.x * vw.w_bstride;
 
   auto slot_point = [&](int s) {  // slot -> point index k = v + S * j
     const int pl = s >> log2pptv, j = s & ((1 << log2pptv) - 1);
@@ -269,9 +282,10 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
     // cut the values loose from the dwordx3 load tuple, otherwise the allocator keeps the triple
     // AND the (x_s, x_s+1) pair copies the packed ops need alive for the whole kernel
     asm volatile("" : "+v"(px[s]), "+v"(py[s]), "+v"(pz[s]));
-    pt[s] = temp[k];
+    pt[s] = vw.init_temp ? 1e10f : temp[k];
     if (WEIGHTED) {
       pwf[s] = weights[k];
+      if (vw.w_is_score) pwf[s] = d6_sigmoid_powf(pwf[s], vw.gamma);
       pw[s] = fmax((double)pwf[s], 1e-12);   // `max(weights[k], 1e-12)` in double, sampling_gpu.cu:466
     }
   }
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
   float cx = 0.f, cy = 0.f, cz = 0.f;
   int first_round = WEIGHTED ? 0 : 1;
   if (!WEIGHTED) {
-    if (h == 0) idxs[0] = 0;
+    if (h == 0) idxs[0] = vw.idx_add;
     cx = xyz[0]; cy = xyz[1]; cz = xyz[2];
   }
 
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
       sz = d6_readlane_f(z2, ww);
     }
     cx = sx; cy = sy; cz = sz;
-    if (h == 0) idxs[r] = old;
+    if (h == 0) idxs[r] = old + vw.idx_add;
   }
   // `temp` is scratch: the reference's callers discard it (pointnet2_utils.py:26-29), so the final
   // min-distances are not written back here (the generic kernels below still do).
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int log2s,
                                                        const float *__restrict__ xyz,
                                                        const float *__restrict__ weights,
                                                        float *__restrict__ temp,
-                                                       int *__restrict__ idxs) {
+                                                       int *__restrict__ idxs, const FpsView vw) {
   __shared__ Slot slots[2][16];
   const int S = 1 << log2s;
   const int h = threadIdx.x;
@@ -376,14 +390,20 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int log2s,
   const int nwaves = (blockDim.x + 63) >> 6;
   const bool live = h < S;
   const int v = (int)bitrev_n((unsigned)h, log2s);
-  xyz += (size_t)blockIdx.x * n * 3;
-  temp += (size_t)blockIdx.x * n;
-  idxs += (size_t)blockIdx.x * m;
-  if (WEIGHTED) weights += (size_t)blockIdx.x * n;
+  xyz += (size_t)blockIdx.x * vw.xyz_bstride;
+  if (temp) temp += (size_t)blockIdx.x * vw.temp_bstride;
+  idxs += (size_t)blockIdx.x * vw.idx_bstride;
+  if (WEIGHTED) weights += (size_t)blockIdx.x * vw.w_bstride;
 
+  auto weight_of = [&](int k) {
+    const float w = weights[k];
+    return vw.w_is_score ? d6_sigmoid_powf(w, vw.gamma) : w;
+  };
+  if (vw.init_temp && live)
+    for (int k = v; k < n; k += S) temp[k] = 1e10f;   // same thread re-reads its own entries: no sync needed
   int old = 0;
   int first_round = WEIGHTED ? 0 : 1;
-  if (!WEIGHTED && h == 0) idxs[0] = 0;
+  if (!WEIGHTED && h == 0) idxs[0] = vw.idx_add;
   for (int r = first_round; r < m; ++r) {
     const float cx = xyz[(size_t)old * 3 + 0], cy = xyz[(size_t)old * 3 + 1], cz = xyz[(size_t)old * 3 + 2];
     float best = live ? -1.0f : -__builtin_inff();
@@ -392,14 +412,14 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int log2s,
       for (int k = v; k < n; k += S) {
         float score;
         if (WEIGHTED && r == 0) {
-          score = weights[k];
+          score = weight_of(k);
         } else {
           const float d = d6_sqdist(xyz[(size_t)k * 3 + 0] - cx, xyz[(size_t)k * 3 + 1] - cy,
                                     xyz[(size_t)k * 3 + 2] - cz);
           const float t = d6_fminf(d, temp[k]);
           temp[k] = t;
           score = t;
-          if (WEIGHTED) score = (float)((double)t * fmax((double)weights[k], 1e-12));
+          if (WEIGHTED) score = (float)((double)t * fmax((double)weight_of(k), 1e-12));
         }
         const bool up = score > best;
         bk = up ? k : bk;
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int log2s,
     const float bmax = d6_wave_max(v2);
     const unsigned long long tie2 = __ballot(v2 == bmax);
     old = d6_readlane_i(i2, __builtin_ctzll(tie2));
-    if (h == 0) idxs[r] = old;
+    if (h == 0) idxs[r] = old + vw.idx_add;
   }
 }
 
@@ -433,9 +453,10 @@ int opt_n_threads_log2(int work_size) {
 
 template <bool W>
 int launch_fps(int b, int n, int m, const float *xyz, const float *weights, float *temp, int *idx,
-               hipStream_t stream) {
-  if (b < 0 || n <= 0 || m < 0 || !xyz || !temp || !idx || (W && !weights)) return DET6D_EINVAL;
-  if (b == 0 || m == 0) return DET6D_OK;
+               const FpsView &vw, hipStream_t stream) {
+  if (b < 0 || n <= 0 || m < 0) return DET6D_EINVAL;
+  if (b == 0 || m == 0) return DET6D_OK;   // nothing to do (empty tensors may carry null pointers)
+  if (!xyz || !idx || (W && !weights) || (!temp && !vw.init_temp)) return DET6D_EINVAL;
   const int log2s = opt_n_threads_log2(n);
   const int S = 1 << log2s;
   const int threads = S < 64 ? 64 : S;
@@ -447,7 +468,7 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
     int lp = 0;                                                                                \
     while ((1 << lp) < ppt) ++lp;                                                              \
     hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), 0, stream, n, m, log2s, \
-                       lp, xyz, weights, temp, idx);                                           \
+                       lp, xyz, weights, temp, idx, vw);                                       \
     return det6d_check_launch("det6d_fps");                                                    \
   } while (0)
   if (n == S * ppt && (ppt & (ppt - 1)) == 0) {
@@ -465,27 +486,62 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
 #undef FPS_FAT
 #define FPS_CASE(P)                                                                          \
   hipLaunchKernelGGL((fps_reg_kernel<P, W>), grid, block, 0, stream, n, m, log2s, xyz, weights, \
-                     temp, idx)
+                     temp, idx, vw)
   if (ppt <= 1) FPS_CASE(1);
   else if (ppt <= 2) FPS_CASE(2);
   else if (ppt <= 4) FPS_CASE(4);
   else if (ppt <= 8) FPS_CASE(8);
   else if (ppt <= kMaxPPT) FPS_CASE(16);
-  else
+  else {
+    if (!temp) return DET6D_EINVAL;  // the memory-resident kernel needs its min-distance scratch
     hipLaunchKernelGGL((fps_mem_kernel<W>), grid, block, 0, stream, n, m, log2s, xyz, weights, temp,
-                       idx);
+                       idx, vw);
+  }
 #undef FPS_CASE
   return det6d_check_launch("det6d_fps");
+}
+
+FpsView dense_view(int n, int m) {
+  FpsView vw;
+  vw.xyz_bstride = (long long)n * 3;
+  vw.w_bstride = n;
+  vw.temp_bstride = n;
+  vw.idx_bstride = m;
+  vw.idx_add = 0;
+  vw.init_temp = 0;
+  vw.w_is_score = 0;
+  vw.gamma = 1.0f;
+  return vw;
 }
 
 }  // namespace
 
 DET6D_API int det6d_fps(int b, int n, int m, const float *xyz, float *temp, int *idx,
                         det6d_stream_t stream) {
-  return launch_fps<false>(b, n, m, xyz, nullptr, temp, idx, (hipStream_t)stream);
+  return launch_fps<false>(b, n, m, xyz, nullptr, temp, idx, dense_view(n, m), (hipStream_t)stream);
 }
 
 DET6D_API int det6d_fps_weights(int b, int n, int m, const float *xyz, const float *weights,
                                 float *temp, int *idx, det6d_stream_t stream) {
-  return launch_fps<true>(b, n, m, xyz, weights, temp, idx, (hipStream_t)stream);
+  return launch_fps<true>(b, n, m, xyz, weights, temp, idx, dense_view(n, m), (hipStream_t)stream);
+}
+
+DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
+                              const float *scores, float gamma, float *temp, int *idx, int idx_stride,
+                              int idx_offset, det6d_stream_t stream) {
+  if (n_total <= 0 || lo < 0 || hi > n_total || hi <= lo || idx_stride < idx_offset + m) return DET6D_EINVAL;
+  const int n = hi - lo;
+  FpsView vw;
+  vw.xyz_bstride = (long long)n_total * 3;
+  vw.w_bstride = n_total;
+  vw.temp_bstride = n;
+  vw.idx_bstride = idx_stride;
+  vw.idx_add = lo;
+  vw.init_temp = 1;
+  vw.w_is_score = 1;
+  vw.gamma = gamma;
+  const float *x = xyz ? xyz + (size_t)lo * 3 : nullptr;
+  int *out = idx ? idx + idx_offset : nullptr;
+  if (scores) return launch_fps<true>(b, n, m, x, scores + lo, temp, out, vw, (hipStream_t)stream);
+  return launch_fps<false>(b, n, m, x, nullptr, temp, out, vw, (hipStream_t)stream);
 }

@@ -100,7 +100,7 @@ int run_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask, int
 
 // ------------------------------------------------------------------------------------------
 // Per-scene post-processing in three short launches over a caller-provided workspace
-// (P <= 512 candidates per scene):
+// (P <= 1024 candidates per scene):
 //   post_rank_kernel   one workgroup per scene: sigmoid, class max, score filter, stable rank
 //                      sort by counting, gather of the sorted boxes;
 //   post_mask_kernel   one WAVE per (sorted row, 64-column block) of the upper-triangular
@@ -109,7 +109,7 @@ int run_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask, int
 //   post_select_kernel one wave per scene: greedy scan over the mask (staged in LDS) + outputs.
 // ------------------------------------------------------------------------------------------
 constexpr int kPostThreads = 256;
-constexpr int kPostMaxP = 512;
+constexpr int kPostMaxP = 1024;
 constexpr int kPostCB = kPostMaxP / 64;
 
 struct PostWs {          // layout of the workspace, per scene
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void post_select_kernel(int p, const float *__r
                                                          float *__restrict__ out_boxes, float *__restrict__ out_scores,
                                                          int *__restrict__ out_labels, int *__restrict__ out_index,
                                                          int *__restrict__ out_count) {
-  __shared__ unsigned long long s_mask[kPostMaxP * kPostCB];
+  extern __shared__ unsigned long long s_mask[];   // p * ceil(p/64) words (dynamic: 8 KB at p=256, 128 KB at 1024)
   __shared__ unsigned long long s_remv[kPostCB];
   __shared__ int s_keep[kPostMaxP];
   const int bi = blockIdx.x, lane = threadIdx.x;
@@ -199,10 +199,11 @@ __global__ __launch_bounds__(64) void post_select_kernel(int p, const float *__r
   boxes += (size_t)bi * p * 9;
   const int cand = ws.cand;
   const int col_blocks = (cand + 63) / 64;
+  const int ldm = (p + 63) / 64;                   // LDS row stride in words
   // stage the rows' live words (own block onward) in LDS: the scan below is a serial chain
-  for (int t = lane; t < cand * kPostCB; t += 64) {
-    const int i = t / kPostCB, w = t % kPostCB;
-    s_mask[t] = (w >= (i >> 6) && w < col_blocks) ? ws.mask[t] : 0ull;
+  for (int t = lane; t < cand * ldm; t += 64) {
+    const int i = t / ldm, w = t % ldm;
+    s_mask[t] = (w >= (i >> 6) && w < col_blocks) ? ws.mask[i * kPostCB + w] : 0ull;
   }
   if (lane < kPostCB) s_remv[lane] = 0ull;
   __syncthreads();
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void post_select_kernel(int p, const float *__r
     if (!((cur >> inblock) & 1ull)) {
       if (lane == 0) s_keep[kept] = i;
       ++kept;
-      if (lane >= nblock && lane < col_blocks) s_remv[lane] |= s_mask[i * kPostCB + lane];
+      if (lane >= nblock && lane < col_blocks) s_remv[lane] |= s_mask[i * ldm + lane];
       __syncthreads();
     }
   }
@@ -313,7 +314,15 @@ DET6D_API int det6d_postprocess(int b, int p, int ncls, const float *cls, const 
   hipLaunchKernelGGL(post_rank_kernel, dim3(b), dim3(kPostThreads), 0, s, p, ncls, cls, boxes, score_thr,
                      pre_max > kPostMaxP ? kPostMaxP : pre_max, ws);
   hipLaunchKernelGGL(post_mask_kernel, dim3(det6d_divup(p, 4), det6d_divup(p, 64), b), dim3(256), 0, s, nms_thr, ws);
-  hipLaunchKernelGGL(post_select_kernel, dim3(b), dim3(64), 0, s, p, boxes, post_max, ws, out_boxes, out_scores,
+  const size_t lds = (size_t)p * ((p + 63) / 64) * sizeof(unsigned long long);
+  static bool big_lds_enabled = false;
+  if (lds > 48 * 1024 && !big_lds_enabled) {   // one-time opt-in for > 64 KB of dynamic LDS (160 KB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute((const void *)post_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kPostMaxP * kPostCB * 8);
+    if (e != hipSuccess) { det6d_set_error("det6d_postprocess hipFuncSetAttribute", e); return DET6D_ELAUNCH; }
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(post_select_kernel, dim3(b), dim3(64), lds, s, p, boxes, post_max, ws, out_boxes, out_scores,
                      out_labels, out_index, out_count);
   return det6d_check_launch("det6d_postprocess");
 }

@@ -147,11 +147,43 @@ __global__ void three_interpolate_grad_kernel(int64_t total, int c, int n, int m
 }
 
 __global__ void pack_points_kernel(int64_t total, int width, int ld, const float *__restrict__ points,
-                                   float *__restrict__ rows) {
+                                   float *__restrict__ rows, float *__restrict__ xyz_out) {
   GRID_STRIDE(i, total) {
     const int c = (int)(i % ld);
     const int64_t r = i / ld;
-    rows[i] = c < width ? points[r * (width + 1) + 1 + c] : 0.f;
+    const float v = c < width ? points[r * (width + 1) + 1 + c] : 0.f;
+    rows[i] = v;
+    if (xyz_out && c < 3) xyz_out[r * 3 + c] = v;
+  }
+}
+
+// centres of a layer: xyz_out[b,j,:] = xyz[b,idx[b,j],:]; optionally the same three columns into the
+// next level's row buffer, whose padding columns [zero_from, ld_rows) are cleared here as well
+__global__ void gather_centres_kernel(int64_t total, int n, int m, int ld_rows, int zero_from,
+                                      const float *__restrict__ xyz, const int *__restrict__ idx,
+                                      float *__restrict__ xyz_out, float *__restrict__ rows_out) {
+  const int per = 3 + (rows_out ? ld_rows - zero_from : 0);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % per);
+    const int64_t bj = i / per;
+    if (c < 3) {
+      const int64_t bi = bj / m;
+      const float v = xyz[(bi * n + idx[bj]) * 3 + c];
+      xyz_out[bj * 3 + c] = v;
+      if (rows_out) rows_out[bj * ld_rows + c] = v;
+    } else {
+      rows_out[bj * ld_rows + zero_from + (c - 3)] = 0.f;
+    }
+  }
+}
+
+// dst[b*m + j, :] = [b, src[b, j, 0:ncol]]   (the reference's (N, 1 + 3) "batch index + xyz" tensors)
+__global__ void with_batch_index_kernel(int64_t total, int m, int ld_src, int ncol,
+                                        const float *__restrict__ src, float *__restrict__ dst) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % (ncol + 1));
+    const int64_t bj = i / (ncol + 1);
+    dst[i] = c == 0 ? (float)(bj / m) : src[bj * ld_src + c - 1];
   }
 }
 
@@ -299,13 +331,35 @@ DET6D_API int det6d_three_interpolate_grad(int b, int c, int n, int m, const flo
 }
 
 DET6D_API int det6d_pack_points(int total, int cin, const float *points, int ld, float *rows,
-                                det6d_stream_t stream) {
+                                float *xyz_out, det6d_stream_t stream) {
   if (total < 0 || cin < 0 || ld < 3 + cin || !points || !rows) return DET6D_EINVAL;
   const int64_t elems = (int64_t)total * ld;
   if (elems == 0) return DET6D_OK;
   hipLaunchKernelGGL(pack_points_kernel, grid_for(elems), dim3(kBlock), 0, S(stream), elems, 3 + cin, ld,
-                     points, rows);
+                     points, rows, xyz_out);
   return det6d_check_launch("det6d_pack_points");
+}
+
+DET6D_API int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, float *xyz_out,
+                                   float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || !xyz || !idx || !xyz_out) return DET6D_EINVAL;
+  if (rows_out && (ld_rows < 3 || zero_from < 3 || zero_from > ld_rows)) return DET6D_EINVAL;
+  const int per = 3 + (rows_out ? ld_rows - zero_from : 0);
+  const int64_t total = (int64_t)b * m * per;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(gather_centres_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, n, m, ld_rows,
+                     zero_from, xyz, idx, xyz_out, rows_out);
+  return det6d_check_launch("det6d_gather_centres");
+}
+
+DET6D_API int det6d_with_batch_index(int b, int m, const float *src, int ld_src, int ncol, float *dst,
+                                     det6d_stream_t stream) {
+  if (b < 0 || m < 0 || ncol <= 0 || ncol > ld_src || !src || !dst) return DET6D_EINVAL;
+  const int64_t total = (int64_t)b * m * (ncol + 1);
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(with_batch_index_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, m, ld_src, ncol,
+                     src, dst);
+  return det6d_check_launch("det6d_with_batch_index");
 }
 
 DET6D_API int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol, const float *rows_in,

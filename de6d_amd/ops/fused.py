@@ -17,8 +17,38 @@ def pack_points(points, ld):
     L.require_cuda(points)
     total, width = points.shape
     rows = torch.empty((total, ld), dtype=torch.float32, device=points.device)
-    L.call("det6d_pack_points", total, width - 4, L.ptr(points), ld, L.ptr(rows), L.stream_ptr())
-    return rows
+    xyz = torch.empty((total, 3), dtype=torch.float32, device=points.device)
+    L.call("det6d_pack_points", total, width - 4, L.ptr(points), ld, L.ptr(rows), L.ptr(xyz), L.stream_ptr())
+    return rows, xyz
+
+
+def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
+    """one sampler of an SA layer: range slice, sigmoid**gamma weights, 1e10 init, +lo offset and the
+    write into the concatenated index buffer all happen inside the kernel"""
+    L.require_cuda(xyz, scores, idx_out)
+    b, n_total, _ = xyz.shape
+    temp = torch.empty((b, hi - lo), dtype=torch.float32, device=xyz.device)
+    L.call("det6d_fps_fused", b, n_total, lo, hi, m, L.ptr(xyz), L.ptr(scores), float(gamma), L.ptr(temp),
+           L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
+
+
+def gather_centres(xyz, idx, rows_out=None, zero_from=0):
+    L.require_cuda(xyz, idx, rows_out)
+    b, n, _ = xyz.shape
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), dtype=torch.float32, device=xyz.device)
+    L.call("det6d_gather_centres", b, n, m, L.ptr(xyz), L.ptr(idx), L.ptr(out), L.ptr(rows_out),
+           rows_out.shape[-1] if rows_out is not None else 0, zero_from, L.stream_ptr())
+    return out
+
+
+def with_batch_index(src, ncol=3):
+    """(B, M, ld) -> (B*M, 1+ncol) rows [b, src[..., :ncol]]"""
+    L.require_cuda(src)
+    b, m, ld = src.shape
+    dst = torch.empty((b * m, ncol + 1), dtype=torch.float32, device=src.device)
+    L.call("det6d_with_batch_index", b, m, L.ptr(src), ld, ncol, L.ptr(dst), L.stream_ptr())
+    return dst
 
 
 def gather_rows(rows_in, idx, ncol, out):

@@ -66,9 +66,7 @@ class PointNet2FSMSG(nn.Module):
     @staticmethod
     def _with_batch_column(x):
         """(B,M,3) -> (B*M,4) rows [batch_idx, x, y, z]"""
-        b, m, _ = x.shape
-        col = torch.arange(b, dtype=torch.float32, device=x.device).view(b, 1, 1).expand(b, m, 1)
-        return torch.cat([col, x], dim=-1).reshape(b * m, 4)
+        return fused.with_batch_index(x, 3)
 
     def forward(self, batch_dict):
         batch_size = batch_dict['batch_size']
@@ -77,8 +75,9 @@ class PointNet2FSMSG(nn.Module):
         n = points.shape[0] // batch_size
         c_in = points.shape[1] - 4
         ld = pointnet2_modules.rows_ld(c_in)
-        rows = fused.pack_points(points.contiguous(), ld).view(batch_size, n, ld)
-        xyz = rows[:, :, :3].contiguous()
+        rows, xyz = fused.pack_points(points.contiguous(), ld)
+        rows = rows.view(batch_size, n, ld)
+        xyz = xyz.view(batch_size, n, 3)
 
         l_xyz, l_rows, l_scores = [xyz], [rows], [None]
         for sa in self.SA_modules:

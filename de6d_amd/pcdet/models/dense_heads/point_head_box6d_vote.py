@@ -127,13 +127,12 @@ class PointHeadBox6DVote(nn.Module):
         vote_flat = vote_xyz.view(b * p, 3)
         boxes = self.box_coder.decode_torch(point_reg_preds, vote_flat)
 
-        bidx = torch.arange(b, dtype=torch.float32, device=rows.device).repeat_interleave(p)
-        cand_xyz = cand_rows[:, :, :3].reshape(b * p, 3)
-        batch_dict['batch_index'] = bidx
-        batch_dict['point_candidate_coords'] = torch.cat([bidx.view(-1, 1), cand_xyz], dim=-1)
-        batch_dict['point_vote_coords'] = torch.cat([bidx.view(-1, 1), vote_flat], dim=-1)
+        cand4 = fused.with_batch_index(cand_rows, 3)
+        batch_dict['batch_index'] = cand4[:, 0]
+        batch_dict['point_candidate_coords'] = cand4
+        batch_dict['point_vote_coords'] = fused.with_batch_index(vote_xyz, 3)
         batch_dict['vote_offsets'] = off_clamped.view(b, p, 3).permute(0, 2, 1).contiguous()
-        batch_dict['point_cls_scores'] = torch.sigmoid(point_cls_preds)
+        batch_dict['point_cls_scores'] = fused.sigmoid_pow(point_cls_preds, 1.0)
         batch_dict['point_box_preds'] = boxes
         batch_dict['batch_cls_preds'] = point_cls_preds
         batch_dict['batch_box_preds'] = boxes

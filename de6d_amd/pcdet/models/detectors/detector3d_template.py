@@ -117,7 +117,7 @@ class Detector3DTemplate(nn.Module):
         fast = (not nms_cfg.MULTI_CLASSES_NMS and nms_cfg.NMS_TYPE == 'nms_gpu'
                 and not batch_dict['cls_preds_normalized'] and not isinstance(cls_preds, list)
                 and box_preds.dim() == 2 and box_preds.shape[1] == 9 and box_preds.shape[0] % batch_size == 0
-                and box_preds.shape[0] // batch_size <= 512 and not cfg.get('OUTPUT_RAW_SCORE', False)
+                and box_preds.shape[0] // batch_size <= 1024 and not cfg.get('OUTPUT_RAW_SCORE', False)
                 and not batch_dict.get('has_class_labels', False))
         if nms_cfg.MULTI_CLASSES_NMS:
             raise NotImplementedError('MULTI_CLASSES_NMS is not used by Det6D configs')
@@ -134,7 +134,7 @@ class Detector3DTemplate(nn.Module):
                 bp = box_preds[mask]
                 cp = cls_preds[mask]
                 if not batch_dict['cls_preds_normalized']:
-                    cp = torch.sigmoid(cp)
+                    cp = fused.sigmoid_pow(cp.contiguous(), 1.0)   # the library's deterministic sigmoid
                 cp, lp = torch.max(cp, dim=-1)
                 lp = batch_dict['roi_labels'][i] if batch_dict.get('has_class_labels', False) else lp + 1
                 sel, sel_scores = model_nms_utils.class_agnostic_nms(cp, bp, nms_cfg, cfg.SCORE_THRESH)

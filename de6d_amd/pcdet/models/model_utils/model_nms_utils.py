@@ -13,7 +13,7 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
     selected = []
     if box_scores.shape[0] > 0:
         k = min(nms_config.NMS_PRE_MAXSIZE, box_scores.shape[0])
-        order = box_scores.sort(0, descending=True, stable=True)[1][:k]  # == topk, ties by index
+        order = torch.sort(box_scores, dim=0, descending=True, stable=True)[1][:k]  # == topk, ties by index
         keep_idx, _ = getattr(iou3d_nms_utils, nms_config.NMS_TYPE)(
             box_preds[order][:, 0:7], box_scores[order], nms_config.NMS_THRESH, **nms_config)
         selected = order[keep_idx[:nms_config.NMS_POST_MAXSIZE]]

@@ -31,7 +31,7 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
 def _nms(boxes, scores, thresh, pre_maxsize, normal):
     assert boxes.shape[1] == 7
     # stable: equal scores keep their original order (the reference's torch.sort is unstable)
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = torch.sort(scores, dim=0, descending=True, stable=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     boxes = boxes[order].contiguous()

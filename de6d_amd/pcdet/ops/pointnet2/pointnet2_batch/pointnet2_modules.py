@@ -139,42 +139,44 @@ class _PointnetSAModuleFSBase(nn.Module):
         return self._folded
 
     # ---- sampling -----------------------------------------------------------------------
-    def _sample_one(self, xyz, scores, lo, hi, method, npoint):
+    def _sample_one(self, xyz, scores, lo, hi, method, npoint, idx_out, offset):
+        """one sampler -> idx_out[:, offset:offset+npoint]; slice, sigmoid**gamma weights, 1e10 init and
+        the + lo offset (pointnet2_modules.py:380,415-424,448) all happen inside det6d_fps_fused"""
         hi = xyz.shape[1] if hi == -1 else hi
-        xyz_slice = xyz[:, lo:hi, :].contiguous()
         if method == 'd-fps':
-            idx = pointnet2_utils.furthest_point_sample(xyz_slice, npoint)
+            fused.fps_fused(xyz, lo, hi, npoint, None, 1.0, idx_out, offset)
         elif method == 's-fps':
             assert scores is not None
-            weights = fused.sigmoid_pow(scores[:, lo:hi].contiguous(), self.weight_gamma)
-            idx = pointnet2_utils.furthest_point_sample_weights(xyz_slice, weights, npoint)
+            fused.fps_fused(xyz, lo, hi, npoint, scores, self.weight_gamma, idx_out, offset)
         else:
             raise NotImplementedError(
                 "sampling method %r is outside the Det6D hot path (SURVEY.md 2.1 #8)" % method)
-        return idx + lo if lo else idx
 
     def _sample(self, xyz, scores):
         """fusion sampling (pointnet2_modules.py:376-450).  The samplers of one layer are independent
         latency chains on one workgroup per scene, so they run concurrently on forked HIP streams
         (also under hipGraph capture, where the fork/join becomes two parallel branches)."""
         jobs = list(zip(self.sample_range_list, self.sample_method_list, self.npoint_list))
+        b = xyz.shape[0]
+        idx = torch.empty((b, sum(self.npoint_list)), dtype=torch.int32, device=xyz.device)
+        offsets = [sum(self.npoint_list[:i]) for i in range(len(jobs))]
         if len(jobs) == 1:
             (lo, hi), method, npoint = jobs[0]
-            return self._sample_one(xyz, scores, lo, hi, method, npoint)
+            self._sample_one(xyz, scores, lo, hi, method, npoint, idx, 0)
+            return idx
         main = torch.cuda.current_stream()
         if self._side_streams is None or len(self._side_streams) < len(jobs) - 1:
             self._side_streams = [torch.cuda.Stream() for _ in range(len(jobs) - 1)]
-        out = [None] * len(jobs)
         for i, ((lo, hi), method, npoint) in enumerate(jobs[1:], start=1):
             side = self._side_streams[i - 1]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                out[i] = self._sample_one(xyz, scores, lo, hi, method, npoint)
+                self._sample_one(xyz, scores, lo, hi, method, npoint, idx, offsets[i])
         (lo, hi), method, npoint = jobs[0]
-        out[0] = self._sample_one(xyz, scores, lo, hi, method, npoint)
+        self._sample_one(xyz, scores, lo, hi, method, npoint, idx, 0)
         for side in self._side_streams[:len(jobs) - 1]:
             main.wait_stream(side)
-        return torch.cat(out, dim=-1)
+        return idx
 
     # ---- fast path ----------------------------------------------------------------------
     def forward_rows(self, xyz, rows, scores=None, new_xyz=None):
@@ -187,11 +189,16 @@ class _PointnetSAModuleFSBase(nn.Module):
             raise NotImplementedError("only max_pool without skip connection is on the Det6D path")
         f = self._prepare(rows.device)
         b, n, _ = xyz.shape
+        new_rows = None
         if new_xyz is None:
             sample_idx = self._sample(xyz, scores)
             m = sample_idx.shape[1]
-            new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=xyz.device)
-            fused.gather_rows(xyz, sample_idx, 3, new_xyz)
+            if f['agg'] is not None:  # next level's rows: xyz now, features by the aggregation GEMM, pad zeroed
+                ld_next = rows_ld(f['out_channels'])
+                new_rows = torch.empty((b, m, ld_next), dtype=torch.float32, device=rows.device)
+                new_xyz = fused.gather_centres(xyz, sample_idx, new_rows, 3 + f['out_channels'])
+            else:
+                new_xyz = fused.gather_centres(xyz, sample_idx)
         m = new_xyz.shape[1]
         pooled = torch.empty((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
         if pooled.shape[1] != f['pooled_width']:
@@ -237,8 +244,9 @@ class _PointnetSAModuleFSBase(nn.Module):
             col += layers[-1][2]
         new_scores = None
         if f['agg'] is not None:
-            new_rows = torch.zeros((b, m, rows_ld(f['out_channels'])), dtype=torch.float32, device=rows.device)
-            new_rows[:, :, :3] = new_xyz
+            if new_rows is None:  # centres supplied by the caller
+                new_rows = torch.zeros((b, m, rows_ld(f['out_channels'])), dtype=torch.float32, device=rows.device)
+                new_rows[:, :, :3] = new_xyz
             run_chain(pooled, f['agg'], out=new_rows, col0=3)
             if f['conf'] is not None:
                 new_scores = run_chain(new_rows, f['conf'])[:, 0].reshape(b, m).contiguous()

@@ -151,8 +151,28 @@ int det6d_nms_to_host(int boxes_num, const float *boxes, float thresh, int64_t *
 /* Pack the reference's flat `points (B*N, 1+3+C)` rows [b,x,y,z,feat..] into the engine's
  * point-major row layout `rows (B,N,ld)` = [x,y,z,feat..,0 pad], ld % 4 == 0.
  * (PointNet2FSMSG.break_up_pc + view/permute, pointnet2_backbone.py:193-224.) */
-int det6d_pack_points(int total, int cin, const float *points, int ld, float *rows,
-                      det6d_stream_t stream);
+int det6d_pack_points(int total, int cin, const float *points, int ld, float *rows, float *xyz_out,
+                      det6d_stream_t stream);   /* xyz_out (total,3) optional packed copy of the coordinates */
+
+/* FPS as the SA layer uses it (pointnet2_modules.py:376-450), one launch per sampler and nothing
+ * else: samples range [lo, hi) of xyz (B, n_total, 3); `scores` == NULL -> d-fps, otherwise s-fps
+ * with weights sigmoid(scores[b, k])**gamma computed in the kernel (scores (B, n_total));
+ * min-distances start at 1e10 implicitly; the picks + lo are written to idx[b*idx_stride +
+ * idx_offset + j].  temp: (B, hi-lo) scratch, needed only when hi-lo is not one of the
+ * register-resident sizes (may be NULL otherwise). */
+int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
+                    float gamma, float *temp, int *idx, int idx_stride, int idx_offset,
+                    det6d_stream_t stream);
+
+/* xyz_out[b,j,:] = xyz[b,idx[b,j],:] and, if rows_out != NULL, the same into columns 0..2 of the next
+ * level's rows (B,m,ld_rows) while clearing its padding columns [zero_from, ld_rows). */
+int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, float *xyz_out,
+                         float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream);
+
+/* dst (b*m, 1+ncol) = [batch index, src[b,j,0:ncol]] — the reference's `point_coords`-style tensors
+ * (pointnet2_backbone.py:236-240,257-261). */
+int det6d_with_batch_index(int b, int m, const float *src, int ld_src, int ncol, float *dst,
+                           det6d_stream_t stream);
 
 /* rows_out[b,j,0:ncol] = rows_in[b, idx[b,j], 0:ncol]   (point-major gather; xyz is ncol=3) */
 int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol, const float *rows_in,
@@ -224,7 +244,7 @@ int det6d_decode_boxes(int rows, int nbin, int ground_aware, int minus, float th
  * i32 1-based, out_index (B,post_max) i32 = index of the kept box inside its scene, out_count (B).
  * `workspace`: det6d_postprocess_workspace_bytes(B) bytes of 16-byte-aligned device scratch
  * (scores, order, sorted boxes, suppression matrix), owned by the caller like every other buffer.
- * P <= 512 (suppression matrix lives in LDS). Equal scores are ordered by ascending original index (the reference uses an
+ * P <= 1024 (the suppression matrix is staged in LDS for the greedy scan). Equal scores are ordered by ascending original index (the reference uses an
  * unstable torch sort there). */
 int64_t det6d_postprocess_workspace_bytes(int b);
 int det6d_postprocess(int b, int p, int ncls, const float *cls, const float *boxes, float score_thr,

@@ -430,13 +430,64 @@ ORACLE_API int det6d_oracle_nms_from_iou(int boxes_num, const float *iou, float 
 
 /* PointNet2FSMSG.break_up_pc + view, core/pcdet/models/backbones_3d/pointnet2_backbone.py:193-224 */
 ORACLE_API int det6d_oracle_pack_points(int total, int cin, const float *points, int ld,
-                                        float *rows) {
+                                        float *rows, float *xyz_out) {
   for (int i = 0; i < total; ++i) {
     const float *src = points + (size_t)i * (1 + 3 + cin);
     float *dst = rows + (size_t)i * ld;
     for (int c = 0; c < 3 + cin; ++c) dst[c] = src[1 + c];
     for (int c = 3 + cin; c < ld; ++c) dst[c] = 0.f;
+    if (xyz_out) for (int c = 0; c < 3; ++c) xyz_out[(size_t)i * 3 + c] = src[1 + c];
   }
+  return 0;
+}
+
+/* sampler of an SA layer as one call (pointnet2_modules.py:376-450): slice, sigmoid**gamma, FPS, + lo */
+ORACLE_API int det6d_oracle_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
+                                      const float *scores, float gamma, float *temp, int *idx,
+                                      int idx_stride, int idx_offset) {
+  const int n = hi - lo;
+  float *sx = (float *)malloc(sizeof(float) * (size_t)n * 3);
+  float *sw = (float *)malloc(sizeof(float) * (size_t)n);
+  float *st = (float *)malloc(sizeof(float) * (size_t)n);
+  int *si = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+  (void)temp;
+  for (int bi = 0; bi < b; ++bi) {
+    memcpy(sx, xyz + ((size_t)bi * n_total + lo) * 3, sizeof(float) * (size_t)n * 3);
+    for (int k = 0; k < n; ++k) st[k] = 1e10f;
+    if (scores) {
+      for (int k = 0; k < n; ++k) sw[k] = d6_sigmoid_powf(scores[(size_t)bi * n_total + lo + k], gamma);
+      det6d_oracle_fps_weights(1, n, m, sx, sw, st, si);
+    } else {
+      det6d_oracle_fps(1, n, m, sx, st, si);
+    }
+    for (int j = 0; j < m; ++j) idx[(size_t)bi * idx_stride + idx_offset + j] = si[j] + lo;
+  }
+  free(sx); free(sw); free(st); free(si);
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_gather_centres(int b, int n, int m, const float *xyz, const int *idx,
+                                           float *xyz_out, float *rows_out, int ld_rows, int zero_from) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      const float *src = xyz + ((size_t)bi * n + idx[(size_t)bi * m + j]) * 3;
+      for (int c = 0; c < 3; ++c) {
+        xyz_out[((size_t)bi * m + j) * 3 + c] = src[c];
+        if (rows_out) rows_out[((size_t)bi * m + j) * ld_rows + c] = src[c];
+      }
+      if (rows_out)
+        for (int c = zero_from; c < ld_rows; ++c) rows_out[((size_t)bi * m + j) * ld_rows + c] = 0.f;
+    }
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_with_batch_index(int b, int m, const float *src, int ld_src, int ncol, float *dst) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      float *d = dst + ((size_t)bi * m + j) * (ncol + 1);
+      d[0] = (float)bi;
+      for (int c = 0; c < ncol; ++c) d[1 + c] = src[((size_t)bi * m + j) * ld_src + c];
+    }
   return 0;
 }
 

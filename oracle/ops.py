@@ -282,8 +282,9 @@ def pack_points(points, ld):
     total, width = p.shape
     cin = width - 4
     rows = np.empty((total, ld), np.float32)
-    lib().det6d_oracle_pack_points(total, cin, _pf(p), ld, _pf(rows))
-    return rows
+    xyz = np.empty((total, 3), np.float32)
+    lib().det6d_oracle_pack_points(total, cin, _pf(p), ld, _pf(rows), _pf(xyz))
+    return rows, xyz
 
 
 def gather_rows(rows_in, idx, ncol, ld_out=None):
@@ -339,3 +340,33 @@ def math_fn(name, x, y=None):
     out = np.empty_like(x)
     lib().det6d_oracle_math(fn, x.size, _pf(x), _pf(y), _pf(out))
     return out
+
+
+def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
+    xyz = _f(xyz)
+    b, n_total, _ = xyz.shape
+    sc = _f(scores) if scores is not None else None
+    assert idx_out.dtype == np.int32 and idx_out.flags.c_contiguous
+    rc = lib().det6d_oracle_fps_fused(b, n_total, lo, hi, m, _pf(xyz), _pf(sc) if sc is not None else None,
+                                      _c_float(gamma), None, _pi(idx_out), idx_out.shape[1], idx_offset)
+    assert rc == 0
+    return idx_out
+
+
+def gather_centres(xyz, idx, ld_rows=0, zero_from=0):
+    xyz, idx = _f(xyz), _i(idx)
+    b, n, _ = xyz.shape
+    m = idx.shape[1]
+    out = np.empty((b, m, 3), np.float32)
+    rows = np.full((b, m, ld_rows), 7.0, np.float32) if ld_rows else None
+    lib().det6d_oracle_gather_centres(b, n, m, _pf(xyz), _pi(idx), _pf(out), _pf(rows) if rows is not None else None,
+                                      ld_rows, zero_from)
+    return out, rows
+
+
+def with_batch_index(src, ncol=3):
+    src = _f(src)
+    b, m, ld = src.shape
+    dst = np.empty((b * m, ncol + 1), np.float32)
+    lib().det6d_oracle_with_batch_index(b, m, _pf(src), ld, ncol, _pf(dst))
+    return dst

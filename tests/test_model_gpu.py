@@ -105,3 +105,48 @@ def test_reference_shaped_sa_forward_matches_rows_path(oracle_ops):
     np.testing.assert_array_equal(nx.cpu().numpy(), rx)
     np.testing.assert_array_equal(nf.cpu().numpy(), rf)
     np.testing.assert_array_equal(ns.cpu().numpy(), rs)
+
+
+def test_waymo_scale_65536_points(oracle_ops):
+    """BASELINE config 5 shapes: 65536-point scene, every per-layer point count x4 (the FPS of the
+    first layer takes the memory-resident generic kernel: N is beyond the register-resident sizes)"""
+    cfg, bd, pred, ref = run_both('synthetic_models/det6d_65536.yaml', 1, 65536, 51)
+    check(bd, pred, ref, 1)
+    assert bd['point_coords_list'][0].shape[0] == 16384 and bd['batch_box_preds'].shape == (1024, 9)
+
+
+def test_ragged_and_tiny_inputs(oracle_ops):
+    """edge cases of the op API: N not a power of two, N < 64, M == N, single point"""
+    from de6d_amd.ops import pointnet2_batch_hip as pn
+    for n, m in [(5000, 128), (333, 333), (63, 10), (2, 2)]:
+        xyz = make_batch(60 + n, 2, max(n, 8))[:, :n, :3].copy()
+        x = torch.from_numpy(xyz).cuda()
+        temp = torch.full((2, n), 1e10, device='cuda')
+        idx = torch.zeros((2, m), dtype=torch.int32, device='cuda')
+        pn.farthest_point_sampling_wrapper(2, n, m, x, temp, idx)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle_ops.fps(xyz, m))
+    # empty batch / zero samples are no-ops
+    e = torch.zeros((0, 8, 3), device='cuda')
+    pn.farthest_point_sampling_wrapper(0, 8, 4, e, torch.zeros((0, 8), device='cuda'), torch.zeros((0, 4), dtype=torch.int32, device='cuda'))
+
+
+def test_graph_replay_equals_eager(oracle_ops):
+    """the hipGraph runner used by bench.py returns exactly the eager detections, replay after replay"""
+    from de6d_amd.runtime import load_config, build_model, GraphedDet6D
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=9, device='cuda')
+    b, n = 2, 2048
+    pts = torch.from_numpy(flat_points(make_batch(90, b, n))).cuda()
+    with torch.no_grad():
+        eager, _ = model({'batch_size': b, 'points': pts})
+    runner = GraphedDet6D(model, b, n)
+    for _ in range(3):
+        got = runner.launch(pts).finalize()
+        for g, e in zip(got, eager):
+            assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+    pts2 = torch.from_numpy(flat_points(make_batch(91, b, n))).cuda()
+    with torch.no_grad():
+        eager2, _ = model({'batch_size': b, 'points': pts2})
+    got2 = runner.launch(pts2).finalize()
+    for g, e in zip(got2, eager2):
+        assert torch.equal(g['pred_boxes'], e['pred_boxes'])

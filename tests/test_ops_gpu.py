@@ -265,3 +265,38 @@ def test_ball_query_pair_matches_two_queries(ext, oracle_ops, n, m, sa, sb):
     np.testing.assert_array_equal(ia.cpu().numpy(), oia)
     np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
     np.testing.assert_array_equal(ib.cpu().numpy(), oib)
+
+
+def test_fused_sampler_and_helpers(ext, oracle_ops):
+    """det6d_fps_fused (range slice + sigmoid**gamma + 1e10 init + offset), gather_centres, with_batch_index, pack"""
+    fused = ext[2]
+    b, n = 2, 4096
+    pts = make_batch(70, b, n, dup_frac=0.1)
+    xyz = np.ascontiguousarray(pts[..., :3])
+    rng = np.random.default_rng(3)
+    scores = (rng.normal(size=(b, n)) * 3).astype(np.float32)
+    for lo, hi, m, sc, gamma, off in [(0, 4096, 512, None, 1.0, 0), (0, 4096, 512, scores, 1.0, 512), (512, 1024, 256, None, 1.0, 0),
+                                      (0, 512, 256, scores, 0.5, 256), (100, 3100, 77, scores, 2.0, 3)]:
+        got = torch.full((b, 1100), -5, dtype=torch.int32, device="cuda")
+        fused.fps_fused(dev(xyz), lo, hi, m, dev(sc) if sc is not None else None, gamma, got, off)
+        want = np.full((b, 1100), -5, np.int32)
+        oracle_ops.fps_fused(xyz, lo, hi, m, sc, gamma, want, off)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        # and it equals the unfused reference sequence
+        sl = np.ascontiguousarray(xyz[:, lo:hi])
+        ref = oracle_ops.fps(sl, m) if sc is None else oracle_ops.fps_weights(sl, oracle_ops.sigmoid_pow(sc[:, lo:hi], gamma), m)
+        np.testing.assert_array_equal(want[:, off:off + m], ref + lo)
+    idx = rng.integers(0, n, (b, 300)).astype(np.int32)
+    rows = torch.full((b, 300, 8), 9.0, device="cuda")
+    cx = fused.gather_centres(dev(xyz), dev(idx), rows, 6)
+    ox, orows = oracle_ops.gather_centres(xyz, idx, 8, 6)
+    np.testing.assert_array_equal(cx.cpu().numpy(), ox)
+    r = rows.cpu().numpy()
+    np.testing.assert_array_equal(r[..., :3], ox)
+    assert (r[..., 3:6] == 9.0).all() and (r[..., 6:] == 0.0).all()
+    np.testing.assert_array_equal(fused.with_batch_index(cx, 3).cpu().numpy(), oracle_ops.with_batch_index(ox, 3))
+    flat = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], pts.reshape(b * n, 4)], 1)
+    rows2, xyz2 = fused.pack_points(dev(flat), 4)
+    orows2, oxyz2 = oracle_ops.pack_points(flat, 4)
+    np.testing.assert_array_equal(rows2.cpu().numpy(), orows2)
+    np.testing.assert_array_equal(xyz2.cpu().numpy(), oxyz2)
