@@ -1,0 +1,294 @@
+// fps_cells.hip — exact, spatially pruned farthest point sampling (D-FPS) for gfx950.
+//
+// Same result, bit for bit, as farthest_point_sampling_kernel
+// (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222) including its tie order,
+// but a round no longer touches every point.
+//
+// Observation.  All min-distances satisfy temp[k] <= M, where M is the value of the previous pick
+// (the current maximum).  A point can only change in this round if d(k, s) < temp[k] <= M.  Points are
+// pre-sorted along a Morton curve and cut into cells of 64 (one wave64 register slot each); a cell
+// whose bounding box is at least sqrt(M) away from the new sample s cannot change, and its cached
+// arg-max stays valid.  The box test is exact in floating point: subtraction, multiplication and fma
+// are monotone, so  lb = fma(gz,gz, fma(gx,gx, gy*gy))  with per-axis gaps g <= |x_k - s| is a true
+// lower bound of the distance the kernel would compute for every point of the cell.
+// After a few hundred picks only ~5 of the 256 cells of a 16384-point scene are touched per round.
+//
+// Structure per round (one workgroup per scene, NW waves, CPW cells per wave, cell g lives in wave
+// g % NW so that neighbouring cells are updated by different waves in parallel):
+//   1. lanes 0..CPW-1 test "their" cell's box against (s, M)          -> ballot = cells to update
+//   2. for each such cell: 7 VALU ops on its 64 points, one DPP max, cache (max, index, xyz) in lane c
+//   3. wave arg-max over the cached cell maxima (lanes 0..CPW-1), one LDS slot per wave, one barrier,
+//      block arg-max over NW slots -> new s, M.
+// Ties (exactly equal maxima: duplicated points) are rare and resolved on a slow path with the
+// reference's order: minimise (bitrev(k mod S), k).
+#include "common.h"
+#include <stdlib.h>
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+__device__ __forceinline__ unsigned bitrev_bits(unsigned v, int bits) {
+  return bits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));
+}
+
+// order key of point k under the reference's tie rule: smaller key wins
+__device__ __forceinline__ unsigned tie_key(int k, int log2s) {
+  return (bitrev_bits((unsigned)k & ((1u << log2s) - 1u), log2s) << (32 - log2s)) | ((unsigned)k >> log2s);
+}
+
+// lane holding the smallest key among the lanes of `cand` (slow path, ties only)
+__device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int log2s) {
+  const int lane = threadIdx.x & 63;
+  const bool mine = (cand >> lane) & 1ull;
+  unsigned key = mine ? tie_key(k, log2s) : 0xFFFFFFFFu;
+  unsigned m = key;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m, off);
+    m = o < m ? o : m;
+  }
+  return __builtin_ctzll(__ballot(mine && key == m));
+}
+
+__device__ __forceinline__ float wmax64(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(t)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+}
+__device__ __forceinline__ float wmin64(float v) { return -wmax64(-v); }
+__device__ __forceinline__ float vmin1(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-pass: Morton order of a scene.  perm[b, p] = original index of the point at sorted position p.
+// Any permutation is CORRECT for the sampler below; the Morton order only makes cells compact.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned part1by1(unsigned v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+template <int IPT>
+__global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bstride, const float *__restrict__ xyz,
+                                                         int *__restrict__ perm) {
+  typedef hipcub::BlockRadixSort<unsigned, 1024, IPT, int> Sort;
+  __shared__ typename Sort::TempStorage sort_tmp;
+  __shared__ float red[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  xyz += (size_t)blockIdx.x * xyz_bstride;
+  perm += (size_t)blockIdx.x * n;
+  float x[IPT], y[IPT];
+  float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int k = tid * IPT + i;
+    x[i] = xyz[(size_t)k * 3 + 0];
+    y[i] = xyz[(size_t)k * 3 + 1];
+    if (x[i] == x[i] && fabsf(x[i]) < 1e30f) { xmin = fminf(xmin, x[i]); xmax = fmaxf(xmax, x[i]); }
+    if (y[i] == y[i] && fabsf(y[i]) < 1e30f) { ymin = fminf(ymin, y[i]); ymax = fmaxf(ymax, y[i]); }
+  }
+  xmin = wmin64(xmin); xmax = wmax64(xmax); ymin = wmin64(ymin); ymax = wmax64(ymax);
+  if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = ymin; red[3][wave] = ymax; }
+  __syncthreads();
+  xmin = red[0][0]; xmax = red[1][0]; ymin = red[2][0]; ymax = red[3][0];
+  for (int w = 1; w < 16; ++w) {
+    xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
+    ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
+  }
+  const float sx = xmax > xmin ? 65535.0f / (xmax - xmin) : 0.f;
+  const float sy = ymax > ymin ? 65535.0f / (ymax - ymin) : 0.f;
+  unsigned key[IPT];
+  int val[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    float fx = (x[i] - xmin) * sx, fy = (y[i] - ymin) * sy;
+    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 65535.f) : 0.f;
+    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 65535.f) : 0.f;
+    key[i] = (part1by1((unsigned)fx) << 1) | part1by1((unsigned)fy);
+    val[i] = tid * IPT + i;
+  }
+  __syncthreads();
+  Sort(sort_tmp).Sort(key, val);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) perm[tid * IPT + i] = val[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The sampler
+// ------------------------------------------------------------------------------------------------
+struct CellSlot {
+  float val;
+  int idx;
+  float x, y, z;
+  float pad[3];
+};
+
+template <int NW, int CPW>
+struct CellState {
+  float px[CPW], py[CPW], pz[CPW], pt[CPW];
+  int pk[CPW];
+  // cached per cell, valid in lane c (c < CPW)
+  float cmax, cbx, cby, cbz;
+  int cidx;
+};
+
+// update cell `c` (wave-uniform): scalar binary search down to the statically indexed slot
+template <int LO, int HI, int NW, int CPW>
+__device__ __forceinline__ void update_cell(int c, CellState<NW, CPW> &st, float cx, float cy, float cz,
+                                            int log2s) {
+  if constexpr (HI - LO == 1) {
+    constexpr int S = LO;
+    const int lane = threadIdx.x & 63;
+    const float d = d6_sqdist(st.px[S] - cx, st.py[S] - cy, st.pz[S] - cz);
+    const float t = vmin1(d, st.pt[S]);
+    st.pt[S] = t;
+    const float v = wmax64(t);
+    const unsigned long long tie = __ballot(t == v);
+    int wl = __builtin_ctzll(tie);
+    if (__popcll(tie) != 1) wl = min_key_lane(tie, st.pk[S], log2s);
+    const float bx = d6_readlane_f(st.px[S], wl), by = d6_readlane_f(st.py[S], wl), bz = d6_readlane_f(st.pz[S], wl);
+    const int bi = d6_readlane_i(st.pk[S], wl);
+    if (lane == c) { st.cmax = v; st.cidx = bi; st.cbx = bx; st.cby = by; st.cbz = bz; }
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (c < MID) update_cell<LO, MID, NW, CPW>(c, st, cx, cy, cz, log2s);
+    else update_cell<MID, HI, NW, CPW>(c, st, cx, cy, cz, log2s);
+  }
+}
+
+template <int NW, int CPW>
+__global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int log2s, long long xyz_bstride,
+                                                            long long temp_bstride, long long idx_bstride,
+                                                            int idx_add, int init_temp, int dbg,
+                                                            const float *__restrict__ xyz,
+                                                            const int *__restrict__ perm,
+                                                            const float *__restrict__ temp,
+                                                            int *__restrict__ idxs) {
+  static_assert(NW <= 16 && CPW <= 32, "layout");
+  __shared__ CellSlot slots[2][NW];
+  const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
+  xyz += (size_t)blockIdx.x * xyz_bstride;
+  perm += (size_t)blockIdx.x * n;
+  if (temp) temp += (size_t)blockIdx.x * temp_bstride;
+  idxs += (size_t)blockIdx.x * idx_bstride;
+
+  CellState<NW, CPW> st;
+  float blo_x = 0.f, blo_y = 0.f, blo_z = 0.f, bhi_x = 0.f, bhi_y = 0.f, bhi_z = 0.f;
+  st.cmax = -1.f; st.cidx = 0; st.cbx = st.cby = st.cbz = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int g = c * NW + wave;              // Morton cell index
+    const int k = perm[g * 64 + lane];
+    st.pk[c] = k;
+    st.px[c] = xyz[(size_t)k * 3 + 0];
+    st.py[c] = xyz[(size_t)k * 3 + 1];
+    st.pz[c] = xyz[(size_t)k * 3 + 2];
+    asm volatile("" : "+v"(st.px[c]), "+v"(st.py[c]), "+v"(st.pz[c]));
+    st.pt[c] = init_temp ? 1e10f : temp[k];
+    const float lx = wmin64(st.px[c]), hx = wmax64(st.px[c]);
+    const float ly = wmin64(st.py[c]), hy = wmax64(st.py[c]);
+    const float lz = wmin64(st.pz[c]), hz = wmax64(st.pz[c]);
+    if (lane == c) { blo_x = lx; bhi_x = hx; blo_y = ly; bhi_y = hy; blo_z = lz; bhi_z = hz; }
+  }
+
+  float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+  float M = __builtin_inff();
+  if (h == 0) idxs[0] = idx_add;
+
+  for (int r = 1; r < m; ++r) {
+    // 1. which of my cells can change?
+    unsigned cells;
+    {
+      const float gx = fmaxf(0.f, fmaxf(blo_x - cx, cx - bhi_x));
+      const float gy = fmaxf(0.f, fmaxf(blo_y - cy, cy - bhi_y));
+      const float gz = fmaxf(0.f, fmaxf(blo_z - cz, cz - bhi_z));
+      const float lb = d6_sqdist(gx, gy, gz);
+      const bool act = lane < CPW && (r == 1 || (!(lb >= M) && dbg != 1));
+      cells = (unsigned)__ballot(act);
+    }
+    // 2. update them
+    while (cells) {
+      const int c = __builtin_ctz(cells);
+      cells &= cells - 1;
+      update_cell<0, CPW, NW, CPW>(c, st, cx, cy, cz, log2s);
+    }
+    // 3. wave arg-max over the cached cell maxima
+    const float cv = lane < CPW ? st.cmax : -__builtin_inff();
+    const float wv = wmax64(cv);
+    const unsigned long long tie = __ballot(cv == wv);
+    int cl = __builtin_ctzll(tie);
+    if (__popcll(tie) != 1) cl = min_key_lane(tie, st.cidx, log2s);
+    CellSlot *sl = slots[r & 1];
+    if (lane == cl) {
+      sl[wave].val = wv;
+      sl[wave].idx = st.cidx;
+      sl[wave].x = st.cbx; sl[wave].y = st.cby; sl[wave].z = st.cbz;
+    }
+    if (dbg != 2) __syncthreads();
+    const int src = lane & (NW - 1);
+    const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
+    const int i2 = sl[src].idx;
+    const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
+    const float bmax = wmax64(v2);
+    const unsigned long long tie2 = __ballot(v2 == bmax);
+    int ww = __builtin_ctzll(tie2);
+    if (__popcll(tie2) != 1) ww = min_key_lane(tie2, i2, log2s);
+    // the reference picks index 0 when nothing exceeds its -1 sentinel (never happens with finite data)
+    const bool found = bmax > -1.0f;
+    const int old = found ? d6_readlane_i(i2, ww) : 0;
+    cx = found ? d6_readlane_f(x2, ww) : xyz[0];
+    cy = found ? d6_readlane_f(y2, ww) : xyz[1];
+    cz = found ? d6_readlane_f(z2, ww) : xyz[2];
+    M = bmax;
+    if (h == 0) idxs[r] = old + idx_add;
+  }
+}
+
+}  // namespace
+
+// Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
+int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
+                           long long idx_bstride, int idx_add, int init_temp, const float *xyz,
+                           const float *temp, int *perm, int *idx, hipStream_t stream) {
+  dim3 grid(b);
+  static const int dbg = getenv("DET6D_FPS_DBG") ? atoi(getenv("DET6D_FPS_DBG")) : 0;  // timing experiments only
+  if (n == 16384) {
+    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    hipLaunchKernelGGL((fps_cells_kernel<8, 32>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride,
+                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
+  } else if (n == 8192) {
+    hipLaunchKernelGGL((cell_sort_kernel<8>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    hipLaunchKernelGGL((fps_cells_kernel<4, 32>), grid, dim3(256), 0, stream, n, m, log2s, xyz_bstride,
+                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
+  } else if (n == 4096) {
+    hipLaunchKernelGGL((cell_sort_kernel<4>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    hipLaunchKernelGGL((fps_cells_kernel<4, 16>), grid, dim3(256), 0, stream, n, m, log2s, xyz_bstride,
+                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
+  } else {
+    return DET6D_EINVAL;
+  }
+  return det6d_check_launch("det6d_fps (cells)");
+}

@@ -158,8 +158,8 @@ int det6d_pack_points(int total, int cin, const float *points, int ld, float *ro
  * else: samples range [lo, hi) of xyz (B, n_total, 3); `scores` == NULL -> d-fps, otherwise s-fps
  * with weights sigmoid(scores[b, k])**gamma computed in the kernel (scores (B, n_total));
  * min-distances start at 1e10 implicitly; the picks + lo are written to idx[b*idx_stride +
- * idx_offset + j].  temp: (B, hi-lo) scratch, needed only when hi-lo is not one of the
- * register-resident sizes (may be NULL otherwise). */
+ * idx_offset + j].  temp: (B, hi-lo) 4-byte scratch (min-distances of the memory-resident kernel, or
+ * the Morton permutation of the pruned cell sampler used for d-fps on 8192 / 16384 points). */
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
                     float gamma, float *temp, int *idx, int idx_stride, int idx_offset,
                     det6d_stream_t stream);

@@ -300,3 +300,18 @@ def test_fused_sampler_and_helpers(ext, oracle_ops):
     orows2, oxyz2 = oracle_ops.pack_points(flat, 4)
     np.testing.assert_array_equal(rows2.cpu().numpy(), orows2)
     np.testing.assert_array_equal(xyz2.cpu().numpy(), oxyz2)
+
+
+def test_pruned_cell_fps_is_exact():
+    """fps_cells.hip (opt-in through DET6D_FPS_CELLS_MIN_N): Morton cells + bounding-box skip test must
+    give the oracle's picks bit for bit, duplicates and all-equal clouds included"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DET6D_FPS_CELLS_MIN_N="4096")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fps_cells.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "exact" in l]
+    assert len(lines) == 7 and all("exact=True" in l or "exact True" in l for l in lines), out.stdout
