@@ -54,8 +54,31 @@ def cpu_baseline(cfg, model, pts_np, scenes):
     omodel.forward(cfg.MODEL, sd, sample, scenes)
     dt = time.time() - t0
     return {"value": scenes / dt, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d scene(s) of the same workload through oracle/model.py (OpenMP GEMM chains on %d threads, "
-                      "index ops single-threaded), %.1f s" % (scenes, os.cpu_count(), dt)}
+            "sample": "%d scene(s) of the same workload through oracle/model.py (OpenMP on %d threads: GEMM chains over "
+                      "rows, FPS over scenes, ball query over centres), %.1f s" % (scenes, os.cpu_count(), dt)}
+
+
+def index_kernel_rates(model, points, batch, n):
+    """pair-evaluations per second of the two search kernels, timed stand-alone with HIP
+    events on their launch stream at the workload's SA1 shapes"""
+    from de6d_amd.ops import fused as F
+    sa = model.backbone_3d.SA_modules[0]
+    m = sum(sa.npoint_list)
+    rows, xyz = F.pack_points(points, 4)
+    xyz = xyz.view(batch, n, 3)
+    idx = torch.empty((batch, m), dtype=torch.int32, device='cuda')
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    F.fps_fused(xyz, 0, n, m, None, 1.0, idx, 0)
+    e[0].record(); F.fps_fused(xyz, 0, n, m, None, 1.0, idx, 0); e[1].record()
+    ctr = F.gather_centres(xyz, idx)
+    shells = [(0.0, sa.radii[0], sa.nsamples[0]), (sa.radii[0], sa.radii[1], sa.nsamples[1])]
+    F.ball_query_pair(xyz, ctr, shells[0], shells[1])
+    e[2].record(); F.ball_query_pair(xyz, ctr, shells[0], shells[1]); e[3].record()
+    torch.cuda.synchronize()
+    t_fps, t_bq = e[0].elapsed_time(e[1]) * 1e-3, e[2].elapsed_time(e[3]) * 1e-3
+    return {"fps_sa1_ms": round(t_fps * 1e3, 3), "fps_pair_evals_per_s": round(batch * (m - 1) * n / t_fps, 0),
+            "ball_query_sa1_ms": round(t_bq * 1e3, 3),
+            "bq_pair_evals_per_s_upper_bound_work": round(2.0 * batch * m * n / t_bq, 0)}
 
 
 def linear_roofline(model, points, batch, flops_per_scene):
@@ -96,7 +119,7 @@ def main():
     ap.add_argument('--points', type=int, default=16384)
     ap.add_argument('--streams', type=int, default=16)
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
-    ap.add_argument('--cpu-scenes', type=int, default=16, help='scenes timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
     args = ap.parse_args()
@@ -188,6 +211,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, points, b, flops)
+            line["index_kernels"] = index_kernel_rates(model, points, b, n)
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

@@ -58,9 +58,10 @@ ORACLE_API int det6d_oracle_fps(int b, int n, int m, const float *xyz, float *te
   if (b < 0 || n <= 0 || m < 0) return -1;
   if (m == 0) return 0;
   const int S = det6d_oracle_opt_n_threads(n);
-  float *dists = (float *)malloc(sizeof(float) * S);
-  int *dists_i = (int *)malloc(sizeof(int) * S);
+#pragma omp parallel for schedule(dynamic)   /* scenes are independent (one CUDA block each) */
   for (int bi = 0; bi < b; ++bi) {
+    float *dists = (float *)malloc(sizeof(float) * S);
+    int *dists_i = (int *)malloc(sizeof(int) * S);
     const float *ds = xyz + (size_t)bi * n * 3;
     float *tp = temp + (size_t)bi * n;
     int *out = idx + (size_t)bi * m;
@@ -86,9 +87,9 @@ ORACLE_API int det6d_oracle_fps(int b, int n, int m, const float *xyz, float *te
       old = dists_i[0];
       out[j] = old;
     }
+    free(dists);
+    free(dists_i);
   }
-  free(dists);
-  free(dists_i);
   return 0;
 }
 
@@ -98,9 +99,10 @@ ORACLE_API int det6d_oracle_fps_weights(int b, int n, int m, const float *xyz, c
   if (b < 0 || n <= 0 || m < 0) return -1;
   if (m == 0) return 0;
   const int S = det6d_oracle_opt_n_threads(n);
-  float *dists = (float *)malloc(sizeof(float) * S);
-  int *dists_i = (int *)malloc(sizeof(int) * S);
+#pragma omp parallel for schedule(dynamic)
   for (int bi = 0; bi < b; ++bi) {
+    float *dists = (float *)malloc(sizeof(float) * S);
+    int *dists_i = (int *)malloc(sizeof(int) * S);
     const float *ds = xyz + (size_t)bi * n * 3;
     const float *w = weights + (size_t)bi * n;
     float *tp = temp + (size_t)bi * n;
@@ -136,9 +138,9 @@ ORACLE_API int det6d_oracle_fps_weights(int b, int n, int m, const float *xyz, c
       old = dists_i[0];
       out[j] = old;
     }
+    free(dists);
+    free(dists_i);
   }
-  free(dists);
-  free(dists_i);
   return 0;
 }
 
@@ -196,6 +198,7 @@ static int ball_query_shell(int b, int n, int m, int dilated, float radius_in, f
                             int *idx) {
   const float rin2 = radius_in * radius_in;
   const float rout2 = radius_out * radius_out;
+#pragma omp parallel for collapse(2) schedule(static)   /* one CUDA thread per (scene, centre) */
   for (int bi = 0; bi < b; ++bi)
     for (int pi = 0; pi < m; ++pi) {
       const float *q = new_xyz + ((size_t)bi * m + pi) * 3;
