@@ -44,6 +44,7 @@ _SIGNATURES = {
     "det6d_ball_query_cnt": [c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P],
     "det6d_ball_query_dilated": [c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P],
     "det6d_ball_query_pair": [c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P],
+    "det6d_ball_query_pair_grid": [c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
     "det6d_group_points": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_group_points_grad": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_three_nn": [c_int, c_int, c_int, _P, _P, _P, _P, _P],
@@ -68,7 +69,8 @@ _SIGNATURES = {
 
 #: every symbol include/det6d_ops.h declares (tests/test_boundary.py checks the export table)
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
-                                                  "det6d_postprocess_workspace_bytes"])
+                                                  "det6d_postprocess_workspace_bytes",
+                                                  "det6d_ball_query_grid_workspace_bytes"])
 
 _lib = None
 
@@ -90,6 +92,8 @@ def lib():
         handle.det6d_last_error.restype = ctypes.c_char_p
         handle.det6d_nms_mask_words.argtypes = [c_int]
         handle.det6d_nms_mask_words.restype = c_int64
+        handle.det6d_ball_query_grid_workspace_bytes.argtypes = [c_int, c_int]
+        handle.det6d_ball_query_grid_workspace_bytes.restype = c_int64
         handle.det6d_postprocess_workspace_bytes.argtypes = [c_int]
         handle.det6d_postprocess_workspace_bytes.restype = c_int64
         _lib = handle

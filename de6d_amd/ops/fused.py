@@ -151,13 +151,30 @@ def nms_device(boxes, thresh, normal=False):
     return keep, num
 
 
-def ball_query_pair(xyz, new_xyz, shell_a, shell_b):
-    """both radius groups of an SA layer in one sweep; shell = (radius_in, radius_out, nsample).
-    Returns (cnt_a, idx_a, cnt_b, idx_b), all int32, fully written by the kernel."""
+#: point count from which the grid-hashed search replaces the brute-force sweep
+GRID_QUERY_MIN_N = 2048
+
+
+def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
+    """both radius groups of an SA layer in one launch; shell = (radius_in, radius_out, nsample).
+    Returns (cnt_a, idx_a, cnt_b, idx_b), all int32, fully written by the kernel.  Large point sets go
+    through the grid-hashed kernel (identical results), small ones through the brute-force sweep."""
     L.require_cuda(xyz, new_xyz)
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
     dev = xyz.device
+    if grid is None:
+        grid = GRID_QUERY_MIN_N <= n <= 98304
+    if grid:
+        cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
+        cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
+        idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)
+        idx_b = torch.empty((b, m, shell_b[2]), dtype=torch.int32, device=dev)
+        ws = torch.empty((int(L.lib().det6d_ball_query_grid_workspace_bytes(b, n)),), dtype=torch.uint8, device=dev)
+        L.call("det6d_ball_query_pair_grid", b, n, m, float(shell_a[0]), float(shell_a[1]), shell_a[2],
+               float(shell_b[0]), float(shell_b[1]), shell_b[2], L.ptr(new_xyz), L.ptr(xyz), L.ptr(ws), L.ptr(cnt_a),
+               L.ptr(idx_a), L.ptr(cnt_b), L.ptr(idx_b), L.stream_ptr())
+        return cnt_a, idx_a, cnt_b, idx_b
     cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
     cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
     idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)

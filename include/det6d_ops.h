@@ -86,6 +86,17 @@ int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns
                           float rout_b, int ns_b, const float *new_xyz, const float *xyz, int *cnt_a,
                           int *idx_a, int *cnt_b, int *idx_b, det6d_stream_t stream);
 
+/* Grid-hashed form of det6d_ball_query_pair for large N (identical results): a uniform (x, y) grid
+ * with cell edge >= max(rout_a, rout_b) is built per scene, a centre tests only the points of its
+ * 3x3 cell neighbourhood, hits are recorded in an N-bit LDS bitmap and read back in ascending index
+ * order.  workspace: det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.
+ * N <= 98304. */
+int64_t det6d_ball_query_grid_workspace_bytes(int b, int n);
+int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
+                               float rout_b, int ns_b, const float *new_xyz, const float *xyz,
+                               void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
+                               det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ grouping ------------- */
 
 /* Replaces group_points_wrapper (group_points_gpu.cu:53-92).

@@ -240,6 +240,16 @@ ORACLE_API int det6d_oracle_ball_query_pair(int b, int n, int m, float rin_a, fl
   return ball_query_shell(b, n, m, 1, rin_b, rout_b, ns_b, new_xyz, xyz, cnt_b, idx_b);
 }
 
+ORACLE_API int64_t det6d_oracle_ball_query_grid_workspace_bytes(int b, int n) { (void)b; (void)n; return 0; }
+ORACLE_API int det6d_oracle_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a,
+                                                 float rin_b, float rout_b, int ns_b, const float *new_xyz,
+                                                 const float *xyz, void *workspace, int *cnt_a, int *idx_a,
+                                                 int *cnt_b, int *idx_b) {
+  (void)workspace;   /* the grid is an acceleration structure only: results are the brute-force ones */
+  return det6d_oracle_ball_query_pair(b, n, m, rin_a, rout_a, ns_a, rin_b, rout_b, ns_b, new_xyz, xyz, cnt_a, idx_a,
+                                      cnt_b, idx_b);
+}
+
 /* group_points_gpu.cu:53-72 group_points_kernel_fast */
 ORACLE_API int det6d_oracle_group_points(int b, int c, int n, int npoints, int nsample,
                                          const float *points, const int *idx, float *out) {

@@ -258,13 +258,14 @@ def test_ball_query_pair_matches_two_queries(ext, oracle_ops, n, m, sa, sb):
     xyz = make_batch(50, b, n, dup_frac=0.05)[..., :3]
     new_xyz = np.ascontiguousarray(xyz[:, :m] + np.float32(0.01))
     new_xyz[:, 0] = 1000.0
-    ca, ia, cb, ib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb)
     oca, oia = oracle_ops.ball_query_dilated(sa[0], sa[1], sa[2], xyz, new_xyz)
     ocb, oib = oracle_ops.ball_query_dilated(sb[0], sb[1], sb[2], xyz, new_xyz)
-    np.testing.assert_array_equal(ca.cpu().numpy(), oca)
-    np.testing.assert_array_equal(ia.cpu().numpy(), oia)
-    np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
-    np.testing.assert_array_equal(ib.cpu().numpy(), oib)
+    for grid in (False, True):   # brute-force sweep and grid-hashed search give the same lists
+        ca, ia, cb, ib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb, grid=grid)
+        np.testing.assert_array_equal(ca.cpu().numpy(), oca)
+        np.testing.assert_array_equal(ia.cpu().numpy(), oia)
+        np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
+        np.testing.assert_array_equal(ib.cpu().numpy(), oib)
 
 
 def test_fused_sampler_and_helpers(ext, oracle_ops):
@@ -315,3 +316,29 @@ def test_pruned_cell_fps_is_exact():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "exact" in l]
     assert len(lines) == 7 and all("exact=True" in l or "exact True" in l for l in lines), out.stdout
+
+
+def test_ball_query_grid_adversarial(ext, oracle_ops):
+    """grid search corner cases: centres outside the cloud, everything in one cell, outliers that stretch
+    the bounding box past 128 cells, vertical stacks (the grid is 2-D), non-finite points"""
+    fused = ext[2]
+    rng = np.random.default_rng(11)
+    n, m = 3000, 200
+    base = (rng.normal(size=(1, n, 3)) * [8, 8, 1]).astype(np.float32)
+    clouds = []
+    c0 = base.copy(); clouds.append(c0)
+    c1 = base.copy(); c1[0, :5, 0] = [500.0, -400.0, 300.0, 250.0, -350.0]; clouds.append(c1)      # far outliers
+    c2 = (base * [0.01, 0.01, 5.0]).astype(np.float32); clouds.append(c2)                         # one cell, tall
+    c3 = base.copy(); c3[0, 7] = np.nan; c3[0, 9, 1] = np.inf; clouds.append(c3)
+    for xyz in clouds:
+        new_xyz = np.ascontiguousarray(xyz[:, :m] + np.float32(0.05))
+        new_xyz[0, 0] = (100.0, 100.0, 0.0)
+        new_xyz[0, 1] = xyz[0, :, :].min(0) - 0.3 if np.isfinite(xyz).all() else (0, 0, 0)
+        for sa, sb in [((0.0, 0.8, 16), (0.8, 1.6, 32)), ((0.0, 4.8, 16), (0.0, 6.4, 32)), ((0.0, 0.05, 8), (0.05, 0.3, 8))]:
+            oca, oia = oracle_ops.ball_query_dilated(sa[0], sa[1], sa[2], xyz, new_xyz)
+            ocb, oib = oracle_ops.ball_query_dilated(sb[0], sb[1], sb[2], xyz, new_xyz)
+            ca, ia, cb, ib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb, grid=True)
+            np.testing.assert_array_equal(ca.cpu().numpy(), oca)
+            np.testing.assert_array_equal(ia.cpu().numpy(), oia)
+            np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
+            np.testing.assert_array_equal(ib.cpu().numpy(), oib)
