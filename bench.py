@@ -109,7 +109,7 @@ def linear_roofline(model, points, batch, flops_per_scene):
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": os.path.basename(pmc[-1]) if pmc and traffic else None,
-            "kernel": "linear_kernel<BN,...> (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
+            "kernel": "linear_kernel<...> + mlp_chain_kernel (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
             "launches_per_step": len(ev), "avg_launch_us": round(total_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_step": round(alg / 1e9, 2), "issued_gflop_per_step": round(issued / 1e9, 2),
             "kernel_ms_per_step": round(total_ms, 3)}

@@ -1,0 +1,214 @@
+// mlp_chain.hip — the three pointwise layers of a NARROW set-abstraction group (all widths <= 64:
+// the first SA layer of Det6D, [4->16->16->32] and [4->32->32->64] on 0.5 M / 1 M rows per batch)
+// fused into one launch: gather -> L1 -> L2 -> L3 -> mask -> max-pool, intermediates never leave
+// the CU.
+//
+// Why a separate kernel: at these widths every layer of the generic GEMM (linear.hip) is bound by
+// writing and re-reading (rows x 32) fp32 intermediates through HBM (~0.8 GB per batch) and by six
+// launches; the arithmetic is only 7.6 GFLOP.
+//
+// Wave-autonomous design: one wave64 owns a 32-row tile (= nsample rows of one centre, or two centres
+// at nsample 16) through all three layers, so there is NO workgroup barrier after the weights are
+// staged.  A layer's 32x32 accumulator tiles (v_mfma_f32_32x32x2_f32: channel on the lane, rows in the
+// registers) are written to a wave-private LDS tile laid out [channel][row] (row stride 33 floats:
+// conflict-free both ways), which is exactly the k-major image the next layer's A fragment
+// (A[i = lane&31][k = lane>>5]) reads with one ds_read_b32.  Weights (<= 13 KB for the three layers)
+// sit in LDS for the whole kernel.
+//
+// Arithmetic is identical to three det6d_linear calls: every output is one ascending-k fmaf chain,
+// + shift, ReLU; masked max over the nsample rows.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kChainWaves = 4;
+constexpr int kTS = 33;       // row stride of the wave-private [channel][row] tiles
+constexpr int kMaxK1 = 8;     // input row width (x,y,z,features + pad)
+constexpr int kMaxC = 32;     // hidden widths
+constexpr int kMaxC3 = 64;    // output width
+
+struct ChainArgs {
+  int rows;                   // b * m * ns
+  int n, m, ns;
+  const float *a; int lda;    // point rows (B, n, lda)
+  const int *idx;             // (B, m, ns)
+  const float *ctr; int ldctr;
+  const int *cnt;             // (B*m)
+  const float *w1, *w2, *w3;  // folded weights, row-major, leading dims ldw1.. (multiples of 4)
+  int ldw1, ldw2, ldw3;
+  const float *s1, *s2, *s3;  // shifts
+  int k1, c1, c2, c3;         // true widths: k1 = lda, c1,c2 <= 32, c3 <= 64
+  float *y; int ldy; int col0;
+};
+
+__device__ __forceinline__ float relu1(float v) { return v > 0.f ? v : 0.f; }
+
+__global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const ChainArgs g) {
+  __shared__ float W1[kMaxK1 * kMaxC];
+  __shared__ float W2[kMaxC * kMaxC];
+  __shared__ float W3[kMaxC * kMaxC3];
+  __shared__ float S1[kMaxC], S2[kMaxC], S3[kMaxC3];
+  __shared__ float T[kChainWaves][2][kMaxC * kTS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  // ---- stage weights (zero padded to the tile widths) ----
+  for (int t = tid; t < kMaxK1 * kMaxC; t += blockDim.x) {
+    const int k = t / kMaxC, c = t % kMaxC;
+    W1[t] = (k < g.k1 && c < g.c1) ? g.w1[(size_t)k * g.ldw1 + c] : 0.f;
+  }
+  for (int t = tid; t < kMaxC * kMaxC; t += blockDim.x) {
+    const int k = t / kMaxC, c = t % kMaxC;
+    W2[t] = (k < g.c1 && c < g.c2) ? g.w2[(size_t)k * g.ldw2 + c] : 0.f;
+  }
+  for (int t = tid; t < kMaxC * kMaxC3; t += blockDim.x) {
+    const int k = t / kMaxC3, c = t % kMaxC3;
+    W3[t] = (k < g.c2 && c < g.c3) ? g.w3[(size_t)k * g.ldw3 + c] : 0.f;
+  }
+  if (tid < kMaxC) { S1[tid] = tid < g.c1 ? g.s1[tid] : 0.f; S2[tid] = tid < g.c2 ? g.s2[tid] : 0.f; }
+  if (tid < kMaxC3) S3[tid] = tid < g.c3 ? g.s3[tid] : 0.f;
+  __syncthreads();
+
+  float *T1 = T[wave][0], *T2 = T[wave][1];
+  const int ntiles = g.rows / 32;
+  const int k1e = (g.k1 + 1) & ~1, c1e = (g.c1 + 1) & ~1, c2e = (g.c2 + 1) & ~1;
+  const int nt3 = (g.c3 + 31) / 32;
+
+  for (int tile = blockIdx.x * kChainWaves + wave; tile < ntiles; tile += gridDim.x * kChainWaves) {
+    const int r = tile * 32 + l31;                 // my row (both lane halves hold the same row)
+    const int cj = r / g.ns;
+    const int bi = cj / g.m;
+    const int p = g.idx[r];
+    const float *src = g.a + ((size_t)bi * g.n + p) * g.lda;
+    const float *c = g.ctr + (size_t)cj * g.ldctr;
+    // ---- layer 1: A' = [xyz - centre, features], K = k1 ----
+    float av[kMaxK1];
+#pragma unroll
+    for (int k = 0; k < kMaxK1; ++k) av[k] = 0.f;
+    {
+      const float4 v0 = *reinterpret_cast<const float4 *>(src);
+      av[0] = v0.x - c[0]; av[1] = v0.y - c[1]; av[2] = v0.z - c[2]; av[3] = v0.w;
+      if (g.k1 > 4) {
+        const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+        av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < kMaxK1 / 2; ++s) {
+      if (2 * s < k1e) {
+        const float a = kh ? av[2 * s + 1] : av[2 * s];
+        const float b = W1[(2 * s + kh) * kMaxC + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+    {
+      const float sh = S1[l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        T1[l31 * kTS + row] = relu1(acc[e] + sh);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 2: K = c1 ----
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int s = 0; s < c1e / 2; ++s) {
+      const float a = T1[(2 * s + kh) * kTS + l31];
+      const float b = W2[(2 * s + kh) * kMaxC + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    {
+      const float sh = S2[l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        T2[l31 * kTS + row] = relu1(acc[e] + sh);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 3: K = c2, N = c3 (1 or 2 column tiles), then mask + max over the nsample rows ----
+    f32x16 acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[j][e] = 0.f;
+    for (int s = 0; s < c2e / 2; ++s) {
+      const float a = T2[(2 * s + kh) * kTS + l31];
+      const float b0 = W3[(2 * s + kh) * kMaxC3 + l31];
+      acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc3[0], 0, 0, 0);
+      if (nt3 > 1) {
+        const float b1 = W3[(2 * s + kh) * kMaxC3 + 32 + l31];
+        acc3[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc3[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= nt3) break;
+      const int col = 32 * j + l31;
+      const bool cok = col < g.c3;
+      const float sh = S3[col];
+      float q[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float mx = relu1(acc3[j][4 * qq] + sh);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+          const float v = relu1(acc3[j][4 * qq + e] + sh);
+          mx = v > mx ? v : mx;
+        }
+        const float o = __shfl_xor(mx, 32);
+        q[qq] = o > mx ? o : mx;
+      }
+      if (g.ns == 32) {
+        float mx = q[0];
+        mx = q[1] > mx ? q[1] : mx; mx = q[2] > mx ? q[2] : mx; mx = q[3] > mx ? q[3] : mx;
+        if (cok && kh == 0) g.y[(size_t)tile * g.ldy + g.col0 + col] = (g.cnt[tile] > 0) ? mx : 0.f;
+      } else {  // ns == 16: two centres per tile
+        const float m0 = q[1] > q[0] ? q[1] : q[0];
+        const float m1 = q[3] > q[2] ? q[3] : q[2];
+        if (cok && kh == 0) {
+          g.y[(size_t)(2 * tile) * g.ldy + g.col0 + col] = (g.cnt[2 * tile] > 0) ? m0 : 0.f;
+          g.y[(size_t)(2 * tile + 1) * g.ldy + g.col0 + col] = (g.cnt[2 * tile + 1] > 0) ? m1 : 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // T1/T2 are rewritten by the next tile
+  }
+}
+
+}  // namespace
+
+DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
+                               const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1,
+                               const float *s1, int c1, const float *w2, int ldw2, const float *s2, int c2,
+                               const float *w3, int ldw3, const float *s3, int c3, float *y, int ldy, int col0,
+                               det6d_stream_t stream) {
+  if (rows < 0 || n <= 0 || m <= 0 || (ns != 16 && ns != 32) || !a || !idx || !ctr || !cnt || !w1 || !w2 || !w3 ||
+      !s1 || !s2 || !s3 || !y)
+    return DET6D_EINVAL;
+  if (lda < 4 || lda > kMaxK1 || (lda & 3) || ((uintptr_t)a & 15) || ldctr < 3) return DET6D_EINVAL;
+  if (c1 <= 0 || c1 > kMaxC || c2 <= 0 || c2 > kMaxC || c3 <= 0 || c3 > kMaxC3) return DET6D_EINVAL;
+  if (ldw1 < c1 || ldw2 < c2 || ldw3 < c3 || rows % (m * ns) || rows % 32) return DET6D_EINVAL;
+  if (rows == 0) return DET6D_OK;
+  ChainArgs g;
+  g.rows = rows; g.n = n; g.m = m; g.ns = ns;
+  g.a = a; g.lda = lda; g.idx = idx; g.ctr = ctr; g.ldctr = ldctr; g.cnt = cnt;
+  g.w1 = w1; g.w2 = w2; g.w3 = w3; g.ldw1 = ldw1; g.ldw2 = ldw2; g.ldw3 = ldw3;
+  g.s1 = s1; g.s2 = s2; g.s3 = s3;
+  g.k1 = lda; g.c1 = c1; g.c2 = c2; g.c3 = c3;
+  g.y = y; g.ldy = ldy; g.col0 = col0;
+  const int ntiles = rows / 32;
+  int blocks = det6d_divup(ntiles, kChainWaves);
+  if (blocks > 256 * 6) blocks = 256 * 6;     // persistent-ish: amortise the weight staging over many tiles
+  hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(64 * kChainWaves), 0, (hipStream_t)stream, g);
+  return det6d_check_launch("det6d_mlp_chain3");
+}

@@ -183,3 +183,28 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
            float(shell_b[1]), shell_b[2], L.ptr(new_xyz), L.ptr(xyz), L.ptr(cnt_a), L.ptr(idx_a), L.ptr(cnt_b),
            L.ptr(idx_b), L.stream_ptr())
     return cnt_a, idx_a, cnt_b, idx_b
+
+
+def chain_eligible(lda, layers, ns):
+    """can a grouped 3-layer MLP run as ONE det6d_mlp_chain3 launch?  layers: [(W, shift, cout, act)] x 3"""
+    return (len(layers) == 3 and lda <= 8 and ns in (16, 32) and layers[0][2] <= 32 and layers[1][2] <= 32
+            and layers[2][2] <= 64 and all(l[3] == 1 for l in layers))
+
+
+def mlp_chain3(rows_pts, idx, ctr, cnt, layers, out, col0):
+    """gather + 3 x (GEMM, shift, ReLU) + mask + max-pool in one launch (narrow widths only)"""
+    L.require_cuda(rows_pts, idx, ctr, cnt, out)
+    b, m, ns = idx.shape
+    (w1, s1, c1, _), (w2, s2, c2, _), (w3, s3, c3, _) = layers
+    ev = None
+    if LINEAR_EVENTS is not None:   # the chain is part of the MLP GEMM family bench.py prices
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    L.call("det6d_mlp_chain3", b * m * ns, rows_pts.shape[1], m, ns, L.ptr(rows_pts), rows_pts.shape[-1], L.ptr(idx),
+           L.ptr(ctr), ctr.shape[-1], L.ptr(cnt), L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
+           L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, L.ptr(out), out.shape[-1], col0, L.stream_ptr())
+    if ev is not None:
+        ev[1].record()
+        r = b * m * ns
+        LINEAR_EVENTS.append((ev[0], ev[1], r, 1, (rows_pts.shape[-1] * c1 + c1 * c2 + c2 * c3)))
+    return out

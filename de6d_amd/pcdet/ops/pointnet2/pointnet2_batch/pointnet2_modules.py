@@ -223,6 +223,10 @@ class _PointnetSAModuleFSBase(nn.Module):
                     pn2.ball_query_cnt_wrapper(b, n, m, rout, nsample, new_xyz, xyz, idx_cnt, idx)
                 found.append((idx_cnt, idx))
         for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
+            if fused.chain_eligible(rows.shape[-1], layers, nsample):   # narrow group: one fused launch
+                fused.mlp_chain3(rows, idx, new_xyz, idx_cnt, layers, pooled, col)
+                col += layers[-1][2]
+                continue
             x = None
             for li, (w, shift, cout, act) in enumerate(layers):
                 last = li == len(layers) - 1

@@ -227,6 +227,16 @@ typedef struct det6d_linear_args {
 } det6d_linear_args;
 int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
 
+/* The three pointwise layers of a NARROW grouped MLP (row width lda <= 8, hidden widths c1, c2 <= 32,
+ * output width c3 <= 64, nsample 16 or 32) in one launch: identical, bit for bit, to
+ *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)
+ * but the (rows x c1), (rows x c2) intermediates stay in LDS (csrc/mlp_chain.hip).
+ * y[(r / ns) * ldy + col0 + c], r over b*m*ns rows. */
+int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
+                     const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1, const float *s1,
+                     int c1, const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
+                     const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream);
+
 /* s-fps weights: w[i] = sigmoid(score[i]) ** gamma  (pointnet2_modules.py:415-419) */
 int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,
                       det6d_stream_t stream);

@@ -588,6 +588,31 @@ ORACLE_API int det6d_oracle_linear(const det6d_linear_args *g) {
   return 0;
 }
 
+/* fused narrow-MLP entry: by definition the three-call sequence */
+ORACLE_API int det6d_oracle_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
+                                       const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1,
+                                       const float *s1, int c1, const float *w2, int ldw2, const float *s2, int c2,
+                                       const float *w3, int ldw3, const float *s3, int c3, float *y, int ldy,
+                                       int col0) {
+  float *h1 = (float *)calloc((size_t)rows * c1 + 1, sizeof(float));
+  float *h2 = (float *)calloc((size_t)rows * c2 + 1, sizeof(float));
+  det6d_linear_args g;
+  memset(&g, 0, sizeof(g));
+  g.mode = 1; g.rows = rows; g.k = lda; g.ncols = c1; g.a = a; g.lda = lda; g.w = w1; g.ldw = ldw1; g.shift = s1;
+  g.act = 1; g.y = h1; g.ldy = c1; g.n = n; g.m = m; g.ns = ns; g.idx = idx; g.ctr = ctr; g.ldctr = ldctr;
+  det6d_oracle_linear(&g);
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = rows; g.k = c1; g.ncols = c2; g.a = h1; g.lda = c1; g.w = w2; g.ldw = ldw2; g.shift = s2;
+  g.act = 1; g.y = h2; g.ldy = c2;
+  det6d_oracle_linear(&g);
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = rows; g.k = c2; g.ncols = c3; g.a = h2; g.lda = c2; g.w = w3; g.ldw = ldw3; g.shift = s3;
+  g.act = 1; g.y = y; g.ldy = ldy; g.col0 = col0; g.pool = ns; g.cnt = cnt;
+  const int rc = det6d_oracle_linear(&g);
+  free(h1); free(h2);
+  return rc;
+}
+
 /* pointnet2_modules.py:415-419 */
 ORACLE_API int det6d_oracle_sigmoid_pow(int count, const float *scores, float gamma, float *weights) {
   for (int i = 0; i < count; ++i) weights[i] = d6_sigmoid_powf(scores[i], gamma);

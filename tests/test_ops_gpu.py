@@ -342,3 +342,37 @@ def test_ball_query_grid_adversarial(ext, oracle_ops):
             np.testing.assert_array_equal(ia.cpu().numpy(), oia)
             np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
             np.testing.assert_array_equal(ib.cpu().numpy(), oib)
+
+
+@pytest.mark.parametrize("c_in,widths,ns", [(1, (16, 16, 32), 16), (1, (32, 32, 64), 32), (4, (24, 32, 40), 16), (1, (8, 16, 16), 32)])
+def test_mlp_chain3_equals_three_linears(ext, oracle_ops, c_in, widths, ns):
+    """the fused narrow-MLP launch against the oracle's three-layer sequence (and hence against three
+    det6d_linear calls, which test_linear_* pins to the same oracle)"""
+    fused = ext[2]
+    b, n, m = 2, 700, 96
+    rng = np.random.default_rng(sum(widths))
+    ld = (3 + c_in + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3 + c_in] = rng.normal(size=(b, n, 3 + c_in))
+    ctr = rng.normal(size=(b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, 3, (b, m)).astype(np.int32)
+    dims = [ld] + list(widths)
+    layers_np, layers_dev = [], []
+    for i in range(3):
+        kin = dims[i] if i == 0 else (dims[i] + 3) // 4 * 4
+        wpad = (dims[i + 1] + 3) // 4 * 4
+        w = np.zeros((kin, wpad), np.float32)
+        w[:dims[i] if i else 3 + c_in, :dims[i + 1]] = rng.normal(size=(dims[i] if i else 3 + c_in, dims[i + 1])) / np.sqrt(dims[i])
+        s = rng.normal(size=(dims[i + 1],)).astype(np.float32)
+        layers_np.append((w, s))
+        layers_dev.append((dev(w), dev(s), dims[i + 1], 1))
+    assert fused.chain_eligible(ld, layers_dev, ns)
+    out = torch.zeros((b * m, widths[2] + 3), device="cuda")
+    fused.mlp_chain3(dev(rows), dev(idx), dev(ctr), dev(cnt), layers_dev, out, 3)
+    h = oracle_ops.linear(rows, layers_np[0][0], layers_np[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(np.ascontiguousarray(np.pad(h, ((0, 0), (0, layers_np[1][0].shape[0] - h.shape[1])))), layers_np[1][0], layers_np[1][1], 1)
+    h = np.ascontiguousarray(np.pad(h[:, :widths[1]], ((0, 0), (0, layers_np[2][0].shape[0] - widths[1]))))
+    ref = np.zeros((b * m, widths[2] + 3), np.float32)
+    oracle_ops.linear(h, layers_np[2][0][:, :widths[2]], layers_np[2][1], 1, cnt=cnt, pool=ns, out=ref, col0=3)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
