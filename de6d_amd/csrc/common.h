@@ -28,24 +28,58 @@ __device__ __forceinline__ float d6_sqdist(float dx, float dy, float dz) {
   return D6_FMA(dz, dz, D6_FMA(dx, dx, dy * dy));
 }
 
-// ---- wave64 cross-lane helpers (DPP, no LDS) ------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float d6_dpp(float keep, float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v),
-                                         CTRL, ROW_MASK, 0xF, false));
+// ---- wave64 cross-lane helpers (DPP, no LDS) ---------------------------------------------------
+// One v_max_f32_dpp per reduction step.  (The builtin form, update_dpp + fmaxf, expands to mov +
+// mov_dpp + two canonicalising max per step.)  Inline asm gets no hazard padding from the compiler: a
+// DPP read of a VGPR written by the previous VALU op needs 2 wait states, hence the s_nop 1.
+// Inputs must not be NaN.
+
+// max over the 64 lanes of a wave; uniform result (read from lane 63)
+__device__ __forceinline__ float d6_wave_max(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(t)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+}
+__device__ __forceinline__ float d6_wave_min(float v) { return -d6_wave_max(-v); }
+
+// max over lanes 0..15 (one DPP row); uniform result (read from lane 0)
+__device__ __forceinline__ float d6_row_max16(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(t)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0));
 }
 
-// max over the 64 lanes of a wave; the result is uniform (returned from lane 63 via readlane).
-// Inputs must not be NaN.
-__device__ __forceinline__ float d6_wave_max(float v) {
-  v = fmaxf(v, d6_dpp<0xB1>(v, v));        // quad_perm [1,0,3,2]
-  v = fmaxf(v, d6_dpp<0x4E>(v, v));        // quad_perm [2,3,0,1]
-  v = fmaxf(v, d6_dpp<0x141>(v, v));       // row_half_mirror
-  v = fmaxf(v, d6_dpp<0x140>(v, v));       // row_mirror   -> every lane holds its row's max
-  v = fmaxf(v, d6_dpp<0x142, 0xA>(v, v));  // row_bcast:15 -> rows 1,3
-  v = fmaxf(v, d6_dpp<0x143, 0xC>(v, v));  // row_bcast:31 -> rows 2,3
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+// v_min_f32 == fminf without the canonicalising v_max the builtin adds for possible signalling NaNs
+__device__ __forceinline__ float d6_vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 __device__ __forceinline__ float d6_readlane_f(float v, int lane) {

@@ -172,52 +172,6 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int log2s,
 }
 
 
-// ---- hand-placed wave64 max reductions: one v_max_f32_dpp per step (hipcc expands the builtin
-// form into mov + mov_dpp + 2 canonicalising max per step).  Inline asm gets no hazard padding
-// from the compiler: a DPP read of a VGPR written by the previous VALU op needs 2 wait states.
-__device__ __forceinline__ float wave_max64_asm(float v) {
-  float t;
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      : "=&v"(t)
-      : "v"(v));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
-}
-// max over lanes 0..15 (one DPP row); result read from lane 0
-__device__ __forceinline__ float row_max16_asm(float v) {
-  float t;
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      : "=&v"(t)
-      : "v"(v));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0));
-}
-__device__ __forceinline__ float vmin_asm(float a, float b) {  // v_min_f32 == fminf, no canonicalise
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // coordinates of slot `ws` (wave-uniform) of lane `wl`: scalar branches down to one slot
@@ -320,7 +274,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int s = 2 * q + e;
-          const float t = vmin_asm(d[e], pt[s]);
+          const float t = d6_vmin(d[e], pt[s]);
           pt[s] = t;
           float score = t;
           if (WEIGHTED) score = (float)((double)t * pw[s]);
@@ -333,7 +287,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
     // a thread that found nothing keeps (-1, k = 0) like the reference's (best = -1, besti = 0)
     const bool found = best > -1.0f;
 
-    const float wmax = wave_max64_asm(best);
+    const float wmax = d6_wave_max(best);
     const unsigned long long tie = __ballot(best == wmax);
     const int wl = __builtin_ctzll(tie);
     const int ws = d6_readlane_i(found ? bs : -1, wl);
@@ -359,7 +313,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
       const float v2 = sl[src].val;
       const int i2 = sl[src].idx;
       const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
-      const float bmax = row_max16_asm(v2);    // NW <= 16: lanes 0..15 hold every wave's entry
+      const float bmax = d6_row_max16(v2);    // NW <= 16: lanes 0..15 hold every wave's entry
       const unsigned long long tie2 = __ballot(v2 == bmax);
       const int ww = __builtin_ctzll(tie2);    // lowest wave among the maxima
       old = d6_readlane_i(i2, ww);

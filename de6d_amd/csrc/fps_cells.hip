@@ -51,33 +51,6 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
   return __builtin_ctzll(__ballot(mine && key == m));
 }
 
-__device__ __forceinline__ float wmax64(float v) {
-  float t;
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      : "=&v"(t)
-      : "v"(v));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
-}
-__device__ __forceinline__ float wmin64(float v) { return -wmax64(-v); }
-__device__ __forceinline__ float vmin1(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Pre-pass: Morton order of a scene.  perm[b, p] = original index of the point at sorted position p.
 // Any permutation is CORRECT for the sampler below; the Morton order only makes cells compact.
@@ -110,7 +83,7 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bs
     if (x[i] == x[i] && fabsf(x[i]) < 1e30f) { xmin = fminf(xmin, x[i]); xmax = fmaxf(xmax, x[i]); }
     if (y[i] == y[i] && fabsf(y[i]) < 1e30f) { ymin = fminf(ymin, y[i]); ymax = fmaxf(ymax, y[i]); }
   }
-  xmin = wmin64(xmin); xmax = wmax64(xmax); ymin = wmin64(ymin); ymax = wmax64(ymax);
+  xmin = d6_wave_min(xmin); xmax = d6_wave_max(xmax); ymin = d6_wave_min(ymin); ymax = d6_wave_max(ymax);
   if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = ymin; red[3][wave] = ymax; }
   __syncthreads();
   xmin = red[0][0]; xmax = red[1][0]; ymin = red[2][0]; ymax = red[3][0];
@@ -163,9 +136,9 @@ __device__ __forceinline__ void update_cell(int c, CellState<NW, CPW> &st, float
     constexpr int S = LO;
     const int lane = threadIdx.x & 63;
     const float d = d6_sqdist(st.px[S] - cx, st.py[S] - cy, st.pz[S] - cz);
-    const float t = vmin1(d, st.pt[S]);
+    const float t = d6_vmin(d, st.pt[S]);
     st.pt[S] = t;
-    const float v = wmax64(t);
+    const float v = d6_wave_max(t);
     const unsigned long long tie = __ballot(t == v);
     int wl = __builtin_ctzll(tie);
     if (__popcll(tie) != 1) wl = min_key_lane(tie, st.pk[S], log2s);
@@ -208,9 +181,9 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
     st.pz[c] = xyz[(size_t)k * 3 + 2];
     asm volatile("" : "+v"(st.px[c]), "+v"(st.py[c]), "+v"(st.pz[c]));
     st.pt[c] = init_temp ? 1e10f : temp[k];
-    const float lx = wmin64(st.px[c]), hx = wmax64(st.px[c]);
-    const float ly = wmin64(st.py[c]), hy = wmax64(st.py[c]);
-    const float lz = wmin64(st.pz[c]), hz = wmax64(st.pz[c]);
+    const float lx = d6_wave_min(st.px[c]), hx = d6_wave_max(st.px[c]);
+    const float ly = d6_wave_min(st.py[c]), hy = d6_wave_max(st.py[c]);
+    const float lz = d6_wave_min(st.pz[c]), hz = d6_wave_max(st.pz[c]);
     if (lane == c) { blo_x = lx; bhi_x = hx; blo_y = ly; bhi_y = hy; blo_z = lz; bhi_z = hz; }
   }
 
@@ -237,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
     }
     // 3. wave arg-max over the cached cell maxima
     const float cv = lane < CPW ? st.cmax : -__builtin_inff();
-    const float wv = wmax64(cv);
+    const float wv = d6_wave_max(cv);
     const unsigned long long tie = __ballot(cv == wv);
     int cl = __builtin_ctzll(tie);
     if (__popcll(tie) != 1) cl = min_key_lane(tie, st.cidx, log2s);
@@ -252,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
     const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
     const int i2 = sl[src].idx;
     const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
-    const float bmax = wmax64(v2);
+    const float bmax = d6_wave_max(v2);
     const unsigned long long tie2 = __ballot(v2 == bmax);
     int ww = __builtin_ctzll(tie2);
     if (__popcll(tie2) != 1) ww = min_key_lane(tie2, i2, log2s);
