@@ -1,23 +1,27 @@
-"""class_agnostic_nms of core/pcdet/models/model_utils/model_nms_utils.py:6-25."""
+"""Class-agnostic NMS helper with the signature of
+core/pcdet/models/model_utils/model_nms_utils.py:6-25 (generic per-scene route; the fused kernel path
+in Detector3DTemplate.post_processing_async does not go through here)."""
 import torch
 
 from ...ops.iou3d_nms import iou3d_nms_utils
 
 
 def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
-    src_box_scores = box_scores
+    """-> (indices into the unfiltered inputs, their scores).  Candidates are the boxes with
+    score >= score_thresh, the best NMS_PRE_MAXSIZE of them in stable descending order; survivors
+    are cut to NMS_POST_MAXSIZE."""
+    all_scores = box_scores
+    kept_src = None
     if score_thresh is not None:
-        scores_mask = (box_scores >= score_thresh)
-        box_scores = box_scores[scores_mask]
-        box_preds = box_preds[scores_mask]
-    selected = []
-    if box_scores.shape[0] > 0:
-        k = min(nms_config.NMS_PRE_MAXSIZE, box_scores.shape[0])
-        order = torch.sort(box_scores, dim=0, descending=True, stable=True)[1][:k]  # == topk, ties by index
-        keep_idx, _ = getattr(iou3d_nms_utils, nms_config.NMS_TYPE)(
-            box_preds[order][:, 0:7], box_scores[order], nms_config.NMS_THRESH, **nms_config)
-        selected = order[keep_idx[:nms_config.NMS_POST_MAXSIZE]]
-    if score_thresh is not None:
-        original_idxs = scores_mask.nonzero().view(-1)
-        selected = original_idxs[selected]
-    return selected, src_box_scores[selected]
+        kept_src = torch.nonzero(box_scores >= score_thresh).view(-1)
+        box_scores, box_preds = box_scores[kept_src], box_preds[kept_src]
+    picked = box_scores.new_zeros((0,), dtype=torch.long)
+    n_cand = int(box_scores.shape[0])
+    if n_cand:
+        top = torch.sort(box_scores, dim=0, descending=True, stable=True)[1][:min(nms_config.NMS_PRE_MAXSIZE, n_cand)]
+        nms_fn = getattr(iou3d_nms_utils, nms_config.NMS_TYPE)
+        keep, _ = nms_fn(box_preds[top][:, :7], box_scores[top], nms_config.NMS_THRESH, **nms_config)
+        picked = top[keep[:nms_config.NMS_POST_MAXSIZE]]
+    if kept_src is not None:
+        picked = kept_src[picked]
+    return picked, all_scores[picked]

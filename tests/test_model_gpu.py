@@ -150,3 +150,29 @@ def test_graph_replay_equals_eager(oracle_ops):
     got2 = runner.launch(pts2).finalize()
     for g, e in zip(got2, eager2):
         assert torch.equal(g['pred_boxes'], e['pred_boxes'])
+
+
+def test_generic_post_processing_route_matches_fused(oracle_ops):
+    """class_agnostic_nms + nms_gpu through the op-level API (the route taken for non-fusable configs)
+    selects the same boxes as the fused post-processing kernels and the oracle"""
+    from de6d_amd.pcdet.config import EasyDict
+    from de6d_amd.pcdet.models.model_utils.model_nms_utils import class_agnostic_nms
+    from de6d_amd.ops import fused
+    from tests.util import random_boxes
+    rng = np.random.default_rng(4)
+    p = 300
+    boxes = np.zeros((p, 9), np.float32)
+    boxes[:, :7] = random_boxes(8, p, spread=25.0)
+    logits = (rng.normal(size=(p, 1)) * 2).astype(np.float32)
+    logits[11] = logits[5]
+    nms_cfg = EasyDict(NMS_TYPE='nms_gpu', NMS_THRESH=0.1, NMS_PRE_MAXSIZE=200, NMS_POST_MAXSIZE=50, MULTI_CLASSES_NMS=False)
+    b, s = torch.from_numpy(boxes).cuda(), fused.sigmoid_pow(torch.from_numpy(logits[:, 0].copy()).cuda(), 1.0)
+    sel, sel_scores = class_agnostic_nms(s, b, nms_cfg, score_thresh=0.3)
+    ob, osc, ol, oi, oc = oracle_ops.postprocess(logits, boxes, 1, 0.3, 200, 50, 0.1)
+    np.testing.assert_array_equal(sel.cpu().numpy(), oi[0, :oc[0]])
+    np.testing.assert_array_equal(sel_scores.cpu().numpy(), osc[0, :oc[0]])
+    fb, fs, fl, fi, fc = fused.postprocess(torch.from_numpy(logits).cuda(), b, 1, 0.3, 200, 50, 0.1)
+    np.testing.assert_array_equal(fi.cpu().numpy(), oi)
+    # nothing above threshold
+    sel, _ = class_agnostic_nms(s, b, nms_cfg, score_thresh=2.0)
+    assert sel.numel() == 0
