@@ -49,8 +49,26 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+#: from this many points on, the cnt / dilated queries go through the grid-hashed kernel
+GRID_QUERY_MIN_N = 2048
+
+
+def _grid_shell(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx):
+    """single shell through det6d_ball_query_pair_grid (second shell empty, outputs discarded)"""
+    import torch
+    dev = xyz.device
+    ws = torch.empty((int(L.lib().det6d_ball_query_grid_workspace_bytes(b, n)),), dtype=torch.uint8, device=dev)
+    junk_cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+    junk_idx = torch.empty((b, m, 1), dtype=torch.int32, device=dev)
+    L.call("det6d_ball_query_pair_grid", b, n, m, radius_in, radius_out, nsample, 0.0, 0.0, 1, L.ptr(new_xyz),
+           L.ptr(xyz), L.ptr(ws), L.ptr(idx_cnt), L.ptr(idx), L.ptr(junk_cnt), L.ptr(junk_idx), _s())
+    return 1
+
+
 def ball_query_cnt_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx_cnt, idx):
     L.require_cuda(new_xyz, xyz, idx_cnt, idx)
+    if GRID_QUERY_MIN_N <= n <= 98304 and nsample <= 128:
+        return _grid_shell(b, n, m, 0.0, radius, nsample, new_xyz, xyz, idx_cnt, idx)
     L.call("det6d_ball_query_cnt", b, n, m, radius, nsample, L.ptr(new_xyz), L.ptr(xyz), L.ptr(idx_cnt),
            L.ptr(idx), _s())
     return 1
@@ -58,6 +76,8 @@ def ball_query_cnt_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx_cnt, idx)
 
 def ball_query_dilated_wrapper(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx):
     L.require_cuda(new_xyz, xyz, idx_cnt, idx)
+    if GRID_QUERY_MIN_N <= n <= 98304 and nsample <= 128:
+        return _grid_shell(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx)
     L.call("det6d_ball_query_dilated", b, n, m, radius_in, radius_out, nsample, L.ptr(new_xyz), L.ptr(xyz),
            L.ptr(idx_cnt), L.ptr(idx), _s())
     return 1
