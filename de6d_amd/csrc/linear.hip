@@ -157,32 +157,47 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   const int arow_s = wm * 32 * TM + l31;
   const int bcol_s = wn * 32 * TN + l31;
 
+  auto kstep = [&](const float *As, const float *Bs, int ks) {
+    float af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = As[(2 * ks + kh) * LDA_S + arow_s + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * ks + kh) * BN + bcol_s + 32 * j];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
   auto compute = [&](int buf) {
     const float *As = As_all + buf * BK * LDA_S;
     const float *Bs = Bs_all + buf * BK * BN;
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(2 * ks + kh) * LDA_S + arow_s + 32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * ks + kh) * BN + bcol_s + 32 * j];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+    for (int ks = 0; ks < BK / 2; ++ks) kstep(As, Bs, ks);
+  };
+  // A short last slab (K = 68, 132, 260: [xyz | C | pad] rows) is peeled out of the main loop and issues
+  // only the k-steps that hold data; the skipped steps would multiply zeros, so every output's chain
+  // is unchanged.  (A branch INSIDE the main loop costs 10-20 %: it breaks the load/MFMA overlap.)
+  auto compute_tail = [&](int kleft) {
+    const int nks = (kleft + 1) >> 1;
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) kstep(As_all, Bs_all, ks);
   };
 
   load_tile(0);
   if (NBUF == 1) {
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    int k0 = 0;
+    for (; k0 + BK <= K; k0 += BK) {
       store_tile(0);
       __syncthreads();
       if (k0 + BK < K) load_tile(k0 + BK);
       compute(0);
       __syncthreads();
+    }
+    if (k0 < K) {
+      store_tile(0);
+      __syncthreads();
+      compute_tail(K - k0);
     }
   } else {
     store_tile(0);
