@@ -86,6 +86,38 @@ def index_kernel_rates(model, points, batch, n):
             "bq_pair_evals_per_s_upper_bound_work": round(2.0 * batch * m * n / t_bq, 0)}
 
 
+def input_producer_rate(cfg, batch, n_raw=120000):
+    """§8 f1 stage timed stand-alone: B raw KITTI-sized frames already in HBM -> the model's points
+    tensor (range mask + sample_points + collate) in one det6d_prepare_points call; HBM roofline on the
+    algorithmic bytes (one read of the raw frames + one write of the sampled rows)"""
+    from de6d_amd.ops import fused as F
+    dc = cfg.DATA_CONFIG
+    n_pts = 16384
+    for p in dc.DATA_PROCESSOR:
+        if p['NAME'] == 'sample_points':
+            n_pts = int(p['NUM_POINTS']['test'])
+    rng = np.random.default_rng(77)
+    r = rng.gamma(2.0, 12.0, batch * n_raw)
+    a = rng.uniform(-np.pi, np.pi, batch * n_raw)
+    raw = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(-1.2, 0.6, batch * n_raw), rng.uniform(0, 1, batch * n_raw)], 1)
+    raw = torch.from_numpy(raw.astype(np.float32)).cuda()
+    offsets = torch.arange(0, batch + 1, dtype=torch.int32, device='cuda') * n_raw
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n_pts, 1)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n_pts, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    alg = batch * (n_raw * 16 + n_pts * 20)
+    return {"ms_per_batch": round(sec * 1e3, 4), "scenes_per_s": round(batch / sec, 0), "raw_points_per_frame": n_raw,
+            "bound": "hbm", "achieved_GBps": round(alg / sec / 1e9, 1), "peak_GBps": 8000.0,
+            "frac": round(alg / sec / 8e12, 4)}
+
+
 def linear_roofline(model, points, batch, flops_per_scene):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel: the SA / head MLP
     GEMMs) measured live with HIP events on the launch stream over one step"""
@@ -217,6 +249,7 @@ def main():
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, points, b, flops)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
+            line["input_producer"] = input_producer_rate(cfg, b)
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

@@ -66,13 +66,16 @@ _SIGNATURES = {
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],
     "det6d_vote_points": [c_int, _P, c_int, _P, c_int, c_float, c_float, c_float, _P, c_int, _P, _P],
     "det6d_decode_boxes": [c_int, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P, _P],
+    "det6d_prepare_points": [c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, c_float,
+                             ctypes.c_uint64, _P, _P, _P, _P],
     "det6d_postprocess": [c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P],
 }
 
 #: every symbol include/det6d_ops.h declares (tests/test_boundary.py checks the export table)
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
                                                   "det6d_postprocess_workspace_bytes",
-                                                  "det6d_ball_query_grid_workspace_bytes"])
+                                                  "det6d_ball_query_grid_workspace_bytes",
+                                                  "det6d_prepare_points_workspace_bytes"])
 
 _lib = None
 
@@ -96,6 +99,8 @@ def lib():
         handle.det6d_nms_mask_words.restype = c_int64
         handle.det6d_ball_query_grid_workspace_bytes.argtypes = [c_int, c_int]
         handle.det6d_ball_query_grid_workspace_bytes.restype = c_int64
+        handle.det6d_prepare_points_workspace_bytes.argtypes = [c_int, c_int]
+        handle.det6d_prepare_points_workspace_bytes.restype = c_int64
         handle.det6d_postprocess_workspace_bytes.argtypes = [c_int]
         handle.det6d_postprocess_workspace_bytes.restype = c_int64
         _lib = handle

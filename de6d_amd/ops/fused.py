@@ -208,3 +208,20 @@ def mlp_chain3(rows_pts, idx, ctr, cnt, layers, out, col0):
         r = b * m * ns
         LINEAR_EVENTS.append((ev[0], ev[1], r, 1, (rows_pts.shape[-1] * c1 + c1 * c2 + c2 * c3)))
     return out
+
+
+def prepare_points(raw, offsets, point_cloud_range, num_points, seed, scene_ids=None, near_depth=40.0):
+    """raw (total_raw, C) concatenated frames + offsets (B+1) int32 -> (points (B*N, 1+C), n_in_range (B))
+    range mask + sample_points + collate batch index in one launch (include/det6d_ops.h: input producer)"""
+    L.require_cuda(raw, offsets, scene_ids)
+    total_raw, c = raw.shape
+    b = offsets.numel() - 1
+    dev = raw.device
+    ws = torch.empty((int(L.lib().det6d_prepare_points_workspace_bytes(b, total_raw)),), dtype=torch.uint8, device=dev)
+    out = torch.empty((b * num_points, 1 + c), dtype=torch.float32, device=dev)
+    n_in = torch.empty((b,), dtype=torch.int32, device=dev)
+    r = [float(v) for v in point_cloud_range]
+    L.call("det6d_prepare_points", b, L.ptr(offsets), L.ptr(scene_ids), total_raw, c, L.ptr(raw), r[0], r[1], r[3], r[4],
+           int(num_points), float(near_depth), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), L.ptr(ws), L.ptr(out),
+           L.ptr(n_in), L.stream_ptr())
+    return out, n_in

@@ -154,6 +154,30 @@ int det6d_nms_normal(int boxes_num, const float *boxes, float thresh, uint64_t *
 int det6d_nms_to_host(int boxes_num, const float *boxes, float thresh, int64_t *keep_host,
                       int normal, det6d_stream_t stream);
 
+/* ------------------------------------------------------------------ input producer ------- */
+/* Raw frames -> the model's `points (B*num_points, 1+C)` tensor [b, x, y, z, feat..] in one launch
+ * (SURVEY.md §8 f1).  Replaces, for the eval/test pipeline,
+ *   DataProcessor.mask_points_and_boxes_outside_range  datasets/processor/data_processor.py:78-90
+ *     (x/y range only: utils/common_utils.py:61-64),
+ *   DataProcessor.sample_points                        data_processor.py:145-178,
+ *   DatasetTemplate.collate_batch ('points' branch)    datasets/dataset.py:171-176,
+ * and moves load_data_to_gpu (models/__init__.py:23-34) in front of them: the caller uploads the RAW
+ * frames `raw (total_raw, c)` with `raw_offsets (b+1)` (device, int32).
+ * Selection rule = the reference's (all points farther than `near_depth` = 40 m kept while they fit,
+ * the rest drawn without replacement from the near ones; short frames padded with duplicates; final
+ * shuffle).  The random draws come from keyed bijections (include/det6d_rng.h) instead of numpy's
+ * global Mersenne Twister, reproducible from (seed, scene id): scene_ids (b, device int32, may be NULL =
+ * position in the batch) names each frame, so a frame is sampled the same way however it is batched
+ * or sharded over GPUs.  A scene with no point in range
+ * yields zero rows (the reference raises).  n_in_range (b) receives the in-range counts.
+ * workspace: det6d_prepare_points_workspace_bytes(b, total_raw) bytes. */
+int64_t det6d_prepare_points_workspace_bytes(int b, int total_raw);
+int det6d_prepare_points(int b, const int *raw_offsets, const int *scene_ids, int total_raw, int c,
+                         const float *raw,
+                         float x_min, float y_min, float x_max, float y_max, int num_points,
+                         float near_depth, uint64_t seed, void *workspace, float *points_out,
+                         int *n_in_range, det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ fused engine ops ----- */
 /* These have no 1:1 reference symbol; they implement the Python-level hot loop of
  * _PointnetSAModuleFSBase.forward (pointnet2_modules.py:462-494) and

@@ -748,3 +748,103 @@ ORACLE_API void det6d_oracle_math(int fn, int count, const float *x, const float
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Input producer: range mask + sample_points + collate 'points' + batch index.
+ *   mask_points_by_range   core/pcdet/utils/common_utils.py:61-64 (x and y only)
+ *   sample_points          core/pcdet/datasets/processor/data_processor.py:145-178
+ *   collate_batch          core/pcdet/datasets/dataset.py:171-176
+ * Written as the reference writes it — build the in-range list, then the `choice` list branch by
+ * branch, then shuffle — with numpy's generator replaced by the keyed bijections of
+ * include/det6d_rng.h:  np.random.choice(S, k, replace=False) := {S[r] : perm_|S|(r) < k} placed at
+ * perm(r);  np.random.choice(S, k, replace=True)[e] := S[randint(e)];  np.random.shuffle :=
+ * slot -> perm_N(slot).
+ * ---------------------------------------------------------------------------------------- */
+#include "../include/det6d_rng.h"
+
+ORACLE_API int det6d_oracle_prepare_points(int b, const int *raw_offsets, const int *scene_ids, int c,
+                                           const float *raw,
+                                           float x_min, float y_min, float x_max, float y_max,
+                                           int num_points, float near_depth, uint64_t seed,
+                                           float *points_out, int *n_in_range) {
+  const int N = num_points;
+  for (int s = 0; s < b; ++s) {
+    const int lo = raw_offsets[s], n_raw = raw_offsets[s + 1] - lo;
+    int *in_idx = (int *)malloc(sizeof(int) * (size_t)(n_raw > 0 ? n_raw : 1));
+    char *is_near = (char *)malloc((size_t)(n_raw > 0 ? n_raw : 1));
+    int *choice = (int *)malloc(sizeof(int) * (size_t)N);
+    int n_in = 0, n_near = 0;
+    for (int i = 0; i < n_raw; ++i) {
+      const float *p = raw + (size_t)(lo + i) * c;
+      if (p[0] >= x_min && p[0] <= x_max && p[1] >= y_min && p[1] <= y_max) {
+        const float depth = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);  /* np.linalg.norm, float32 */
+        is_near[n_in] = depth < near_depth;
+        n_near += is_near[n_in];
+        in_idx[n_in++] = i;
+      }
+    }
+    n_in_range[s] = n_in;
+    float *out = points_out + (size_t)s * N * (1 + c);
+    if (n_in == 0) {
+      for (int k = 0; k < N; ++k) {
+        out[(size_t)k * (1 + c)] = (float)s;
+        for (int j = 0; j < c; ++j) out[(size_t)k * (1 + c) + 1 + j] = 0.f;
+      }
+      free(in_idx); free(is_near); free(choice);
+      continue;
+    }
+    const uint32_t sid = scene_ids ? (uint32_t)scene_ids[s] : (uint32_t)s;
+    const uint32_t key_sel = d6_stream_key(seed, sid, 1);
+    const uint32_t key_shuffle = d6_stream_key(seed, sid, 2);
+    const uint32_t key_extra = d6_stream_key(seed, sid, 3);
+    const int n_far = n_in - n_near;
+    if (N < n_in) {
+      if (N > n_far) {  /* near_idxs_choice = choice(near, N - n_far, replace=False); concat(near_choice, far) */
+        const int k = N - n_far;
+        int r_near = 0, r_far = 0;
+        for (int r = 0; r < n_in; ++r) {
+          if (is_near[r]) {
+            const uint32_t p = d6_perm((uint32_t)r_near++, (uint32_t)n_near, key_sel);
+            if (p < (uint32_t)k) choice[p] = in_idx[r];
+          } else {
+            choice[k + r_far++] = in_idx[r];
+          }
+        }
+      } else {          /* choice(arange(len(points)), N, replace=False) */
+        for (int r = 0; r < n_in; ++r) {
+          const uint32_t p = d6_perm((uint32_t)r, (uint32_t)n_in, key_sel);
+          if (p < (uint32_t)N) choice[p] = in_idx[r];
+        }
+      }
+    } else {            /* arange(len(points)) + extra_choice */
+      const int extra = N - n_in;
+      for (int r = 0; r < n_in; ++r) choice[r] = in_idx[r];
+      if (extra > n_in) {
+        for (int e = 0; e < extra; ++e) choice[n_in + e] = in_idx[d6_randint((uint32_t)e, (uint32_t)n_in, key_extra)];
+      } else {
+        for (int r = 0; r < n_in; ++r) {
+          const uint32_t p = d6_perm((uint32_t)r, (uint32_t)n_in, key_sel);
+          if (p < (uint32_t)extra) choice[n_in + p] = in_idx[r];
+        }
+      }
+    }
+    for (int slot = 0; slot < N; ++slot) {  /* np.random.shuffle(choice); points[choice]; batch-index pad */
+      const uint32_t pos = d6_perm((uint32_t)slot, (uint32_t)N, key_shuffle);
+      float *dst = out + (size_t)pos * (1 + c);
+      const float *src = raw + (size_t)(lo + choice[slot]) * c;
+      dst[0] = (float)s;
+      for (int j = 0; j < c; ++j) dst[1 + j] = src[j];
+    }
+    free(in_idx); free(is_near); free(choice);
+  }
+  return 0;
+}
+
+/* the keyed bijection itself, for the unit tests (bijectivity, key sensitivity) */
+ORACLE_API void det6d_oracle_perm(uint32_t n, uint64_t seed, uint32_t scene, uint32_t purpose, uint32_t *out) {
+  const uint32_t key = d6_stream_key(seed, scene, purpose);
+  for (uint32_t x = 0; x < n; ++x) out[x] = d6_perm(x, n, key);
+}
+
+/* the CPU restatement needs no scratch */
+ORACLE_API int64_t det6d_oracle_prepare_points_workspace_bytes(int b, int total_raw) { (void)b; (void)total_raw; return 0; }

@@ -370,3 +370,29 @@ def with_batch_index(src, ncol=3):
     dst = np.empty((b * m, ncol + 1), np.float32)
     lib().det6d_oracle_with_batch_index(b, m, _pf(src), ld, ncol, _pf(dst))
     return dst
+
+
+def prepare_points(frames, point_cloud_range, num_points, seed, near_depth=40.0, scene_ids=None):
+    """frames: list of (n_i, C) raw frames -> (points (B*N, 1+C), n_in_range (B))"""
+    import ctypes
+    frames = [_f(f) for f in frames]
+    b, c = len(frames), frames[0].shape[1]
+    offsets = np.zeros(b + 1, np.int32)
+    offsets[1:] = np.cumsum([f.shape[0] for f in frames])
+    raw = np.ascontiguousarray(np.concatenate(frames, axis=0)) if offsets[-1] else np.zeros((1, c), np.float32)
+    out = np.empty((b * num_points, 1 + c), np.float32)
+    n_in = np.zeros(b, np.int32)
+    r = [float(v) for v in point_cloud_range]
+    ids = None if scene_ids is None else _i(scene_ids)
+    lib().det6d_oracle_prepare_points(b, _pi(offsets), None if ids is None else _pi(ids), c, _pf(raw), _c_float(r[0]), _c_float(r[1]), _c_float(r[3]),
+                                      _c_float(r[4]), int(num_points), _c_float(near_depth), ctypes.c_uint64(seed),
+                                      _pf(out), _pi(n_in))
+    return out, n_in
+
+
+def perm(n, seed, scene=0, purpose=2):
+    import ctypes
+    out = np.empty(n, np.uint32)
+    lib().det6d_oracle_perm(ctypes.c_uint32(n), ctypes.c_uint64(seed), ctypes.c_uint32(scene), ctypes.c_uint32(purpose),
+                            out.ctypes.data_as(ctypes.c_void_p))
+    return out

@@ -8,6 +8,11 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    + keep lists from the greedy scan of iou3d_nms.cpp:116-132 applied to them
   box_coder.npz    (code, points) -> boxes9 from the reference's PointBinResidual6DCoder.decode_torch
                    (core/pcdet/utils/box_coder_utils.py imported standalone)
+  producer.npz     raw frames -> ids chosen by the reference's OWN DataProcessor
+                   (mask_points_and_boxes_outside_range + sample_points, data_processor.py:78-90,145-178,
+                   np.random seeded) in each of its four branches; the parts of the result that do not
+                   depend on the generator (in-range set, kept far points, multiplicities) pin the
+                   selection rule of det6d_prepare_points
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -245,9 +250,60 @@ def gen_model():
     print("det6d_car_state_dict.json", len(keys), "entries")
 
 
+# ----------------------------------------------------------------------------- input producer
+def producer_frame(seed, n, x_hi=80.0):
+    """(n, 4) frame [x, y, z, id]: the last column is a unique id so rows can be traced"""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-10, x_hi, n), rng.uniform(-50, 50, n), rng.uniform(-3, 1, n),
+                     np.arange(n)], 1).astype(np.float32)
+
+
+PRODUCER_CASES = {  # name: (frame seed, raw points, x upper bound, NUM_POINTS)
+    'keep_far': (1, 3000, 55.0, 1500),     # N < n_in and N > n_far: all far + random near
+    'any_subset': (2, 3000, 80.0, 600),    # N <= n_far: random subset of everything
+    'pad_once': (3, 1500, 80.0, 1400),     # n_in <= N <= 2 n_in: duplicates drawn without replacement
+    'pad_many': (4, 400, 80.0, 1024),      # N > 2 n_in: duplicates drawn with replacement
+}
+
+
+def gen_producer():
+    EasyDict = install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pcdet.datasets.processor.data_processor import DataProcessor
+    pc_range = np.array([0, -40, -3, 70.4, 40, 1], np.float32)
+    out = {'point_cloud_range': pc_range}
+    for name, (seed, n, x_hi, num_points) in PRODUCER_CASES.items():
+        cfgs = [EasyDict(NAME='mask_points_and_boxes_outside_range', REMOVE_OUTSIDE_BOXES=True),
+                EasyDict(NAME='sample_points', NUM_POINTS=EasyDict(train=num_points, test=num_points)),
+                EasyDict(NAME='shuffle_points', SHUFFLE_ENABLED=EasyDict(train=True, test=False))]
+        dp = DataProcessor(cfgs, point_cloud_range=pc_range, training=False, num_point_features=4)
+        frame = producer_frame(seed, n, x_hi)
+        np.random.seed(1000 + seed)
+        res = dp.forward({'points': frame.copy()})['points']
+        assert res.shape == (num_points, 4)
+        ids = res[:, 3].astype(np.int64)
+        assert np.array_equal(res, frame[ids])
+        masked = dp.mask_points_and_boxes_outside_range({'points': frame.copy()}, config=cfgs[0])['points']
+        in_ids = masked[:, 3].astype(np.int64)
+        depth = np.linalg.norm(masked[:, 0:3], axis=1)
+        n_in, n_far = len(in_ids), int((depth >= 40.0).sum())
+        branch = ('keep_far' if num_points > n_far else 'any_subset') if num_points < n_in else \
+                 ('pad_many' if num_points - n_in > n_in else 'pad_once')
+        assert branch == name, (name, branch, n_in, n_far)
+        out[name + '_frame'] = frame
+        out[name + '_num_points'] = np.int64(num_points)
+        out[name + '_in_ids'] = in_ids
+        out[name + '_far_ids'] = in_ids[depth >= 40.0]
+        out[name + '_chosen_ids'] = ids
+    np.savez_compressed(os.path.join(HERE, "producer.npz"), **out)
+    print("producer.npz", {k: PRODUCER_CASES[k][3] for k in PRODUCER_CASES})
+
+
 if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
     gen_nms()
     gen_box_coder()
     gen_model()
+    gen_producer()
