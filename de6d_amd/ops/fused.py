@@ -225,3 +225,13 @@ def prepare_points(raw, offsets, point_cloud_range, num_points, seed, scene_ids=
            int(num_points), float(near_depth), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), L.ptr(ws), L.ptr(out),
            L.ptr(n_in), L.stream_ptr())
     return out, n_in
+
+
+def kitti_annos(boxes, scene_of, calib):
+    """boxes (T, >=7) LiDAR detections, scene_of (T) int32, calib (B, 28) -> (T, 12)
+    [camera box x,y,z,l,h,w,ry | image box x1,y1,x2,y2 | alpha]  (include/det6d_ops.h: output consumer)"""
+    L.require_cuda(boxes, scene_of, calib)
+    total, ld = boxes.shape
+    out = torch.empty((total, 12), dtype=torch.float32, device=boxes.device)
+    L.call("det6d_kitti_annos", total, L.ptr(boxes), ld, L.ptr(scene_of), L.ptr(calib), L.ptr(out), L.stream_ptr())
+    return out

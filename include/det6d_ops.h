@@ -178,6 +178,19 @@ int det6d_prepare_points(int b, const int *raw_offsets, const int *scene_ids, in
                          float near_depth, uint64_t seed, void *workspace, float *points_out,
                          int *n_in_range, det6d_stream_t stream);
 
+/* ------------------------------------------------------------------ output consumer ------ */
+/* Detections of a batch (LiDAR frame) -> KITTI annotation fields in one launch:
+ * the device half of KittiDataset.generate_prediction_dicts (datasets/kitti/kitti_dataset.py:277-351;
+ * slopedkitti/kitti_dataset.py:299-379), i.e. box_utils.boxes3d_lidar_to_kitti_camera (box_utils.py:196-212),
+ * boxes3d_kitti_camera_to_imageboxes (:261-281) with Calibration.lidar_to_rect / rect_to_img
+ * (calibration_kitti.py:64-83), and alpha (kitti_dataset.py:319).
+ * boxes (total, ld >= 7) [x,y,z,dx,dy,dz,heading,..]; scene_of (total) int32 = row of `calib`;
+ * calib (B, 28) float32 per scene: M = V2C^T R0^T (4x3 row-major), P2 (3x4 row-major), image height,
+ * image width (<= 0: no clipping), 2 pad.  annos_out (total, 12): camera box [x,y,z,l,h,w,ry],
+ * image box [x1,y1,x2,y2], alpha.  float32; tolerance vs the NumPy reference 1e-4 (BLAS dot order). */
+int det6d_kitti_annos(int total, const float *boxes, int ld, const int *scene_of, const float *calib,
+                      float *annos_out, det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ fused engine ops ----- */
 /* These have no 1:1 reference symbol; they implement the Python-level hot loop of
  * _PointnetSAModuleFSBase.forward (pointnet2_modules.py:462-494) and

@@ -848,3 +848,55 @@ ORACLE_API void det6d_oracle_perm(uint32_t n, uint64_t seed, uint32_t scene, uin
 
 /* the CPU restatement needs no scratch */
 ORACLE_API int64_t det6d_oracle_prepare_points_workspace_bytes(int b, int total_raw) { (void)b; (void)total_raw; return 0; }
+
+/* ------------------------------------------------------------------------------------------
+ * Output consumer: detections -> KITTI annotation fields, float32.
+ *   boxes3d_lidar_to_kitti_camera       core/pcdet/utils/box_utils.py:196-212
+ *   boxes3d_to_corners3d_kitti_camera   box_utils.py:215-258 (bottom_center=True)
+ *   boxes3d_kitti_camera_to_imageboxes  box_utils.py:261-281
+ *   Calibration.lidar_to_rect/rect_to_img  core/pcdet/utils/calibration_kitti.py:64-83
+ *   alpha = -arctan2(-y, x) + ry        core/pcdet/datasets/kitti/kitti_dataset.py:319
+ * Scalar form with every dot product as an ascending fma chain and the shared det6d_math.h
+ * sincos / atan2 (the NumPy reference uses BLAS and libm; oracle/annos.py is the literal NumPy
+ * restatement that is pinned to the reference, and this function is checked against it to 1e-4).
+ * ---------------------------------------------------------------------------------------- */
+ORACLE_API int det6d_oracle_kitti_annos(int total, const float *boxes, int ld, const int *scene_of,
+                                        const float *calib, float *annos_out) {
+  for (int t = 0; t < total; ++t) {
+    const float *b = boxes + (size_t)t * ld;
+    const float *c = calib + (size_t)scene_of[t] * 28;
+    const float *M = c, *P = c + 12;
+    const float img_h = c[24], img_w = c[25];
+    const float x = b[0], y = b[1], l = b[3], w = b[4], h = b[5], heading = b[6];
+    const float z = b[2] - h / 2.f;
+    float cam[3];
+    for (int j = 0; j < 3; ++j) cam[j] = D6_FMA(z, M[6 + j], D6_FMA(y, M[3 + j], x * M[j])) + M[9 + j];
+    const float ry = -heading - 1.57079632679489661923f;
+    float sn, cs;
+    d6_sincosf(ry, &sn, &cs);
+    /* reference corner tables (box_utils.py:230-234) */
+    const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sz[8] = {1, -1, -1, 1, 1, -1, -1, 1};
+    float u0 = 3.0e38f, v0 = 3.0e38f, u1 = -3.0e38f, v1 = -3.0e38f;
+    for (int k = 0; k < 8; ++k) {
+      const float xc = sx[k] * l / 2.f, zc = sz[k] * w / 2.f, yc = k < 4 ? 0.f : -h;
+      const float px = cam[0] + D6_FMA(zc, sn, xc * cs);
+      const float py = cam[1] + yc;
+      const float pz = cam[2] + D6_FMA(zc, cs, -xc * sn);
+      const float hu = D6_FMA(pz, P[2], D6_FMA(py, P[1], px * P[0])) + P[3];
+      const float hv = D6_FMA(pz, P[6], D6_FMA(py, P[5], px * P[4])) + P[7];
+      const float u = hu / pz, v = hv / pz;
+      u0 = d6_fminf(u0, u); u1 = d6_fmaxf(u1, u);
+      v0 = d6_fminf(v0, v); v1 = d6_fmaxf(v1, v);
+    }
+    if (img_w > 0.f) {
+      u0 = d6_fminf(d6_fmaxf(u0, 0.f), img_w - 1.f); u1 = d6_fminf(d6_fmaxf(u1, 0.f), img_w - 1.f);
+      v0 = d6_fminf(d6_fmaxf(v0, 0.f), img_h - 1.f); v1 = d6_fminf(d6_fmaxf(v1, 0.f), img_h - 1.f);
+    }
+    float *o = annos_out + (size_t)t * 12;
+    o[0] = cam[0]; o[1] = cam[1]; o[2] = cam[2];
+    o[3] = l; o[4] = h; o[5] = w; o[6] = ry;
+    o[7] = u0; o[8] = v0; o[9] = u1; o[10] = v1;
+    o[11] = -d6_atan2f(-y, x) + ry;
+  }
+  return 0;
+}

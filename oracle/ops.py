@@ -396,3 +396,11 @@ def perm(n, seed, scene=0, purpose=2):
     lib().det6d_oracle_perm(ctypes.c_uint32(n), ctypes.c_uint64(seed), ctypes.c_uint32(scene), ctypes.c_uint32(purpose),
                             out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+def kitti_annos(boxes, scene_of, calib):
+    """C-oracle mirror of det6d_kitti_annos: boxes (T, ld), scene_of (T) int32, calib (B, 28) -> (T, 12)"""
+    boxes, calib, scene_of = _f(boxes), _f(calib), _i(scene_of)
+    out = np.empty((boxes.shape[0], 12), np.float32)
+    lib().det6d_oracle_kitti_annos(boxes.shape[0], _pf(boxes), boxes.shape[1], _pi(scene_of), _pf(calib), _pf(out))
+    return out

@@ -13,6 +13,8 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    np.random seeded) in each of its four branches; the parts of the result that do not
                    depend on the generator (in-range set, kept far points, multiplicities) pin the
                    selection rule of det6d_prepare_points
+  annos.npz        detections -> KITTI annotation dicts and label-file lines from the reference's OWN
+                   KittiDataset / SlopedKittiDataSet.generate_prediction_dicts (+ box_utils, Calibration)
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -300,6 +302,69 @@ def gen_producer():
     print("producer.npz", {k: PRODUCER_CASES[k][3] for k in PRODUCER_CASES})
 
 
+# ----------------------------------------------------------------------------- output consumer
+def kitti_calib(seed):
+    """a KITTI-like calibration (values of the order of sequence 0000xx), slightly perturbed per seed"""
+    rng = np.random.default_rng(seed)
+    P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884]], np.float32)
+    R0 = np.array([[0.9999239, 0.00983776, -0.007445048], [-0.009869795, 0.9999421, -0.004278459],
+                   [0.007402527, 0.004351614, 0.9999631]], np.float32)
+    V2C = np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766], [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                    [0.9998621, 0.00752379, 0.01480755, -0.2717806]], np.float32)
+    P2[:, 3] += rng.normal(0, 0.01, 3).astype(np.float32)
+    V2C[:, 3] += rng.normal(0, 0.01, 3).astype(np.float32)
+    return {'P2': P2, 'R0': R0, 'Tr_velo2cam': V2C, 'P3': P2.copy()}
+
+
+def annos_inputs():
+    frames = []
+    for i, k in enumerate((37, 0, 5)):
+        rng = np.random.default_rng(500 + i)
+        boxes = random_boxes(600 + i, max(k, 1), spread=30.0)[:k]
+        boxes[:, 0] = np.abs(boxes[:, 0]) + 4.0           # in front of the camera
+        pitch = np.where(rng.uniform(size=k) < 0.5, 0.0, -rng.uniform(0.17, 0.4, k))
+        b9 = np.concatenate([boxes, pitch[:, None], np.zeros((k, 1))], 1).astype(np.float32)
+        frames.append(dict(boxes=b9, scores=rng.uniform(0.1, 1.0, k).astype(np.float32),
+                           labels=rng.integers(1, 4, k).astype(np.int64), calib=kitti_calib(i),
+                           image_shape=np.array([375 - i, 1242 - 2 * i], np.int32), frame_id='%06d' % (7 + i)))
+    return frames
+
+
+def gen_annos():
+    import tempfile
+    from pathlib import Path
+    install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pcdet.datasets.kitti.kitti_dataset import KittiDataset
+    from pcdet.datasets.slopedkitti.kitti_dataset import SlopedKittiDataset
+    from pcdet.utils.calibration_kitti import Calibration
+    names = ['Car', 'Pedestrian', 'Cyclist']
+    frames = annos_inputs()
+    out = {'n_frames': np.int64(len(frames))}
+    for tag, cls, ncol in (('kitti', KittiDataset, 7), ('sloped', SlopedKittiDataset, 9)):
+        batch = {'frame_id': [f['frame_id'] for f in frames], 'calib': [Calibration(f['calib']) for f in frames],
+                 'image_shape': torch.from_numpy(np.stack([f['image_shape'] for f in frames]))}
+        preds = [{'pred_boxes': torch.from_numpy(f['boxes'][:, :ncol].copy()), 'pred_scores': torch.from_numpy(f['scores']),
+                  'pred_labels': torch.from_numpy(f['labels'])} for f in frames]
+        with tempfile.TemporaryDirectory() as tmp:
+            annos = cls.generate_prediction_dicts(batch, preds, names, output_path=Path(tmp))
+            for i, (f, a) in enumerate(zip(frames, annos)):
+                for key in ('alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score', 'boxes_lidar', 'pitch', 'roll'):
+                    if key in a:
+                        out['%s_%d_%s' % (tag, i, key)] = np.asarray(a[key])
+                out['%s_%d_name' % (tag, i)] = np.asarray(a['name']).astype('U16')
+                out['%s_%d_txt' % (tag, i)] = np.array(open(os.path.join(tmp, f['frame_id'] + '.txt')).read())
+    for i, f in enumerate(frames):
+        for key in ('boxes', 'scores', 'labels', 'image_shape'):
+            out['in_%d_%s' % (i, key)] = f[key]
+        for key in ('P2', 'R0', 'Tr_velo2cam'):
+            out['in_%d_%s' % (i, key)] = f['calib'][key]
+        out['in_%d_frame_id' % i] = np.array(f['frame_id'])
+    np.savez_compressed(os.path.join(HERE, "annos.npz"), **out)
+    print("annos.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
@@ -307,3 +372,4 @@ if __name__ == "__main__":
     gen_box_coder()
     gen_model()
     gen_producer()
+    gen_annos()
