@@ -69,6 +69,8 @@ _SIGNATURES = {
     "det6d_prepare_points": [c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, c_float,
                              ctypes.c_uint64, _P, _P, _P, _P],
     "det6d_kitti_annos": [c_int, _P, c_int, _P, _P, _P, _P],
+    "det6d_make_slope": [c_int, _P, c_int, c_int, _P, _P, _P],
+    "det6d_boxes9_corners": [c_int, _P, _P, _P],
     "det6d_postprocess": [c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P],
 }
 

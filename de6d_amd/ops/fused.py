@@ -235,3 +235,24 @@ def kitti_annos(boxes, scene_of, calib):
     out = torch.empty((total, 12), dtype=torch.float32, device=boxes.device)
     L.call("det6d_kitti_annos", total, L.ptr(boxes), ld, L.ptr(scene_of), L.ptr(calib), L.ptr(out), L.stream_ptr())
     return out
+
+
+def make_slope(points, boxes9, params):
+    """in-place SlopeAug geometry: points (N, >=3) float32 cuda, boxes9 (M, 9) float64 cuda (or None),
+    params 16 host doubles (include/det6d_ops.h: SlopeAug geometry)"""
+    import numpy as np
+    L.require_cuda(points, boxes9)
+    prm = np.ascontiguousarray(params, np.float64)
+    assert prm.size == 16 and points.dtype == torch.float32 and (boxes9 is None or boxes9.dtype == torch.float64)
+    n_boxes = 0 if boxes9 is None else boxes9.shape[0]
+    L.call("det6d_make_slope", points.shape[0], L.ptr(points), points.shape[1], n_boxes, L.ptr(boxes9),
+           prm.ctypes.data_as(ctypes.c_void_p), L.stream_ptr())
+
+
+def boxes9_corners(boxes9):
+    """(M, 9) float64 cuda [x,y,z,dx,dy,dz,rz,ry,rx] -> (M, 8, 3) float64 corners"""
+    L.require_cuda(boxes9)
+    assert boxes9.dtype == torch.float64
+    out = torch.empty((boxes9.shape[0], 8, 3), dtype=torch.float64, device=boxes9.device)
+    L.call("det6d_boxes9_corners", boxes9.shape[0], L.ptr(boxes9), L.ptr(out), L.stream_ptr())
+    return out

@@ -191,6 +191,22 @@ int det6d_prepare_points(int b, const int *raw_offsets, const int *scene_ids, in
 int det6d_kitti_annos(int total, const float *boxes, int ld, const int *scene_of, const float *calib,
                       float *annos_out, det6d_stream_t stream);
 
+/* ------------------------------------------------------------------ SlopeAug geometry ---- */
+/* Per-point / per-box half of random_global_make_slope (datasets/augmentor/augmentor_utils.py:670-694,
+ * SURVEY.md §8 f4): points (n_points, ld) float32 and boxes9 (n_boxes, 9) float64
+ * [x,y,z,dx,dy,dz,rz,ry,rx] are updated IN PLACE.  params (16 doubles, HOST memory, read at call time):
+ * pivot xyz [0:3], rotation matrix R row-major [3:12] (= Rotation.from_rotvec(angle).as_matrix()),
+ * k = angle_y / (angle_x + 1e-6) [12], sensor side sign(k (0 - x0) + y0) [13], pitch / roll increments
+ * (euler 'XYZ' [1], [0]) [14], [15].  Everything with sign(k (x - x0) + y0 - y) != side is rotated about
+ * the pivot; all box angles are wrapped to [-pi, pi) (common_utils.limit_period).  NumPy's dtype
+ * behaviour is kept (float32 points updated through float64 temporaries).  Tolerance vs NumPy 1e-6. */
+int det6d_make_slope(int n_points, float *points, int ld, int n_boxes, double *boxes9, const double *params,
+                     det6d_stream_t stream);
+
+/* corners (n_boxes, 8, 3) float64 of 9-D boxes, R = Rx(rx) Ry(ry) Rz(rz) (scipy 'zyx', extrinsic): box_utils.boxes3d_to_corners_3d
+ * (core/pcdet/utils/box_utils.py:57-71). */
+int det6d_boxes9_corners(int n_boxes, const double *boxes9, double *corners, det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ fused engine ops ----- */
 /* These have no 1:1 reference symbol; they implement the Python-level hot loop of
  * _PointnetSAModuleFSBase.forward (pointnet2_modules.py:462-494) and

@@ -900,3 +900,73 @@ ORACLE_API int det6d_oracle_kitti_annos(int total, const float *boxes, int ld, c
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SlopeAug geometry, scalar mirrors of det6d_make_slope / det6d_boxes9_corners.
+ *   random_global_make_slope (non-smooth branch)  core/pcdet/datasets/augmentor/augmentor_utils.py:670-694
+ *   boxes3d_to_corners_3d                          core/pcdet/utils/box_utils.py:57-71
+ * oracle/slope.py is the literal NumPy/scipy restatement pinned to the reference's own output;
+ * these functions are checked against it to 1e-6 and against the HIP kernels bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+static double o_sgn(double v) { return (double)((v > 0.0) - (v < 0.0)); }
+/* NumPy stores the intermediate results into the float32 array: force the rounding (gcc 11 -O3's SLP
+ * vectoriser was seen to drop a (double)(float) round trip here) */
+static __attribute__((noinline)) double o_f32(double v) { volatile float f = (float)v; return (double)f; }
+static void o_rot3(const double *R, double x, double y, double z, double *o) {
+  for (int j = 0; j < 3; ++j) o[j] = fma(z, R[3 * j + 2], fma(y, R[3 * j + 1], x * R[3 * j]));
+}
+/* limit_period runs in float32 in the reference (check_numpy_to_torch casts to float): each op rounds to float */
+static double o_wrap_pi(double v) {
+  const float p = 6.283185307179586f, x = (float)v;
+  const float q = floorf(x / p + 0.5f);
+  const float t = q * p;
+  return (double)(x - t);
+}
+
+ORACLE_API int det6d_oracle_make_slope(int n_points, float *points, int ld, int n_boxes, double *boxes9,
+                                       const double *params) {
+  const double *pivot = params, *R = params + 3;
+  const double k = params[12], x0 = params[0], y0 = params[1], side = params[13];
+  for (int i = 0; i < n_points; ++i) {
+    float *p = points + (size_t)i * ld;
+    const double x = p[0], y = p[1];
+    if (o_sgn(k * (x - x0) + y0 - y) == side) continue;
+    const double fx = o_f32(x - pivot[0]), fy = o_f32(y - pivot[1]), fz = o_f32((double)p[2] - pivot[2]);
+    double r[3];
+    o_rot3(R, fx, fy, fz, r);
+    p[0] = (float)o_f32(o_f32(r[0]) + pivot[0]);
+    p[1] = (float)o_f32(o_f32(r[1]) + pivot[1]);
+    p[2] = (float)o_f32(o_f32(r[2]) + pivot[2]);
+  }
+  for (int i = 0; i < n_boxes; ++i) {
+    double *b = boxes9 + (size_t)i * 9;
+    if (o_sgn(k * (b[0] - x0) + y0 - b[1]) != side) {
+      double r[3];
+      o_rot3(R, b[0] - pivot[0], b[1] - pivot[1], b[2] - pivot[2], r);
+      b[0] = r[0] + pivot[0]; b[1] = r[1] + pivot[1]; b[2] = r[2] + pivot[2];
+      b[7] += params[14];
+      b[8] += params[15];
+    }
+    b[6] = o_wrap_pi(b[6]); b[7] = o_wrap_pi(b[7]); b[8] = o_wrap_pi(b[8]);
+  }
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_boxes9_corners(int n_boxes, const double *boxes9, double *corners) {
+  static const double tx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, ty[8] = {1, -1, -1, 1, 1, -1, -1, 1},
+                      tz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+  for (int i = 0; i < n_boxes; ++i) {
+    const double *b = boxes9 + (size_t)i * 9;
+    const double cz = cos(b[6]), sz = sin(b[6]), cy = cos(b[7]), sy = sin(b[7]), cx = cos(b[8]), sx = sin(b[8]);
+    const double R[9] = {cy * cz, -cy * sz, sy,
+                         cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy,
+                         sx * sz - cx * sy * cz, sx * cz + cx * sy * sz, cx * cy};
+    for (int k = 0; k < 8; ++k) {
+      double r[3];
+      o_rot3(R, tx[k] * b[3] * 0.5, ty[k] * b[4] * 0.5, tz[k] * b[5] * 0.5, r);
+      double *o = corners + ((size_t)i * 8 + k) * 3;
+      o[0] = r[0] + b[0]; o[1] = r[1] + b[1]; o[2] = r[2] + b[2];
+    }
+  }
+  return 0;
+}

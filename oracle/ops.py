@@ -404,3 +404,21 @@ def kitti_annos(boxes, scene_of, calib):
     out = np.empty((boxes.shape[0], 12), np.float32)
     lib().det6d_oracle_kitti_annos(boxes.shape[0], _pf(boxes), boxes.shape[1], _pi(scene_of), _pf(calib), _pf(out))
     return out
+
+
+def make_slope(points, boxes9, params):
+    """C-oracle mirror of det6d_make_slope; returns updated copies"""
+    pts = np.array(points, np.float32, copy=True, order='C')
+    bx = np.array(boxes9, np.float64, copy=True, order='C')
+    prm = np.ascontiguousarray(params, np.float64)
+    dp = ctypes.c_void_p
+    lib().det6d_oracle_make_slope(pts.shape[0], pts.ctypes.data_as(dp), pts.shape[1], bx.shape[0], bx.ctypes.data_as(dp),
+                                  prm.ctypes.data_as(dp))
+    return pts, bx
+
+
+def boxes9_corners(boxes9):
+    bx = np.ascontiguousarray(boxes9, np.float64)
+    out = np.empty((bx.shape[0], 8, 3), np.float64)
+    lib().det6d_oracle_boxes9_corners(bx.shape[0], bx.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out

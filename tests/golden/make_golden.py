@@ -15,6 +15,8 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    selection rule of det6d_prepare_points
   annos.npz        detections -> KITTI annotation dicts and label-file lines from the reference's OWN
                    KittiDataset / SlopedKittiDataSet.generate_prediction_dicts (+ box_utils, Calibration)
+  slope.npz        SlopeAug: (boxes, points, seed) -> sloped boxes / points from the reference's OWN
+                   augmentor_utils.random_global_make_slope (plain and smooth) and box_utils.boxes3d_to_corners_3d
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -365,6 +367,33 @@ def gen_annos():
     print("annos.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- SlopeAug
+def gen_slope():
+    install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pcdet.datasets.augmentor import augmentor_utils as ref_aug
+    from pcdet.utils import box_utils as ref_box
+    from tests.util import make_scene
+    out = {}
+    params = (20.0, 10.0, *np.deg2rad([20.0, 8.0]))
+    out['params'] = np.array(params)
+    for case, (seed, smooth) in enumerate(((1, False), (2, False), (3, True), (4, True))):
+        points = make_scene(700 + case, 2048)
+        boxes = random_boxes(800 + case, 24, spread=35.0).astype(np.float32)
+        boxes[:, 0] = np.abs(boxes[:, 0]) + 2.0
+        np.random.seed(seed)
+        gt, pts, pivot, angle = ref_aug.random_global_make_slope(boxes.copy(), points.copy(), params=params, smooth=smooth)
+        out['in_%d_points' % case], out['in_%d_boxes' % case] = points, boxes
+        out['in_%d_seed' % case], out['in_%d_smooth' % case] = np.int64(seed), np.bool_(smooth)
+        out['out_%d_points' % case], out['out_%d_boxes' % case] = pts, gt
+        out['out_%d_pivot' % case], out['out_%d_angle' % case] = np.asarray(pivot), np.asarray(angle)
+        out['out_%d_corners' % case] = ref_box.boxes3d_to_corners_3d(gt.copy())
+    np.savez_compressed(os.path.join(HERE, "slope.npz"), **out)
+    print("slope.npz", len(out), "arrays; moved points per case:",
+          [int((out['out_%d_points' % c] != out['in_%d_points' % c]).any(1).sum()) for c in range(4)])
+
+
 if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
@@ -373,3 +402,4 @@ if __name__ == "__main__":
     gen_model()
     gen_producer()
     gen_annos()
+    gen_slope()
