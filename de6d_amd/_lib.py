@@ -35,6 +35,18 @@ class LinearArgs(ctypes.Structure):
 
 
 _P = c_void_p
+class EvalMatchArgs(ctypes.Structure):
+    """det6d_eval_match_args (include/det6d_ops.h)"""
+    _fields_ = [("n_frames", ctypes.c_int), ("n_thresh", ctypes.c_int), ("metric", ctypes.c_int),
+                ("compute_aos", ctypes.c_int), ("dt_f32", ctypes.c_int), ("min_overlap", ctypes.c_double),
+                ("thresholds", ctypes.c_void_p), ("dt_off", ctypes.c_void_p), ("gt_off", ctypes.c_void_p),
+                ("dc_off", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("overlaps", ctypes.c_void_p),
+                ("gt_alpha", ctypes.c_void_p), ("dt_bbox", ctypes.c_void_p), ("dt_alpha", ctypes.c_void_p),
+                ("dt_score", ctypes.c_void_p), ("ignored_gt", ctypes.c_void_p), ("ignored_dt", ctypes.c_void_p),
+                ("dc_bbox", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+                ("tp_scores", ctypes.c_void_p), ("tp_count", ctypes.c_void_p), ("gt_of_tp", ctypes.c_void_p)]
+
+
 _SIGNATURES = {
     "det6d_fps": [c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_fps_weights": [c_int, c_int, c_int, _P, _P, _P, _P, _P],
@@ -71,6 +83,9 @@ _SIGNATURES = {
     "det6d_kitti_annos": [c_int, _P, c_int, _P, _P, _P, _P],
     "det6d_make_slope": [c_int, _P, c_int, c_int, _P, _P, _P],
     "det6d_boxes9_corners": [c_int, _P, _P, _P],
+    "det6d_eval_overlaps": [c_int, c_int, _P, _P, _P, c_int64, _P, _P, c_int, _P, _P],
+    "det6d_eval_match": [ctypes.POINTER(EvalMatchArgs), _P],
+    "det6d_eval_reduce": [c_int, c_int, _P, _P, _P],
     "det6d_postprocess": [c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P],
 }
 

@@ -6,8 +6,8 @@ same label-file lines.  The reference converts every frame on the host (three `.
 frame, NumPy box/camera math); here the whole batch is converted by one kernel launch
 (det6d_kitti_annos) and pulled with one device-to-host copy.
 
-Loading KITTI from disk, info/database generation and the numba evaluators are not part of this
-path (SURVEY.md §8 f3 is the evaluator row).
+`evaluation` runs the AP evaluator on the device (kitti_object_eval_python/eval.py).
+Loading KITTI from disk and info / database generation are not part of this path.
 """
 import numpy as np
 import torch
@@ -106,6 +106,16 @@ class KittiDataset(object):
                         print(line, file=f)
         return annos
 
-    def evaluation(self, det_annos, class_names, **kwargs):
-        raise NotImplementedError('KITTI AP evaluation is SURVEY.md §8 f3 (not built); result.pkl / label files '
-                                  'written by eval_one_epoch are in the reference format for the reference tooling')
+    EVAL_FUNCTION = 'get_official_eval_result'
+
+    def evaluation(self, det_annos, class_names, gt_annos=None, **kwargs):
+        """AP report + dictionary (kitti_dataset.py:353-363 / slopedkitti :385-394) through the device evaluator.
+        Ground truth comes from `self.kitti_infos[i]['annos']` like in the reference, or from `gt_annos`."""
+        import copy
+        from .kitti_object_eval_python import eval as kitti_eval
+        if gt_annos is None:
+            infos = getattr(self, 'kitti_infos', None)
+            if not infos or 'annos' not in infos[0].keys():
+                return None, {}
+            gt_annos = [info['annos'] for info in infos]
+        return getattr(kitti_eval, self.EVAL_FUNCTION)(copy.deepcopy(gt_annos), copy.deepcopy(det_annos), class_names)

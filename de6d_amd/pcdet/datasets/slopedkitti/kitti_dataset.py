@@ -5,3 +5,4 @@ from ..kitti.kitti_dataset import KittiDataset
 
 class SlopedKittiDataset(KittiDataset):
     EXTRA_FIELDS = ('pitch', 'roll')
+    EVAL_FUNCTION = 'get_slopedkitti_eval_result'

@@ -94,8 +94,10 @@ def eval_one_epoch(cfg, model, dataloader, epoch_id, logger, dist_test=False, sa
         result_str, result_dict = dataset.evaluation(det_annos, class_names,
                                                      eval_metric=cfg.MODEL.POST_PROCESSING.EVAL_METRIC,
                                                      output_path=final_output_dir)
-    except NotImplementedError as err:   # evaluators are SURVEY.md §8 f3
+    except NotImplementedError as err:   # a dataset without ground truth
         result_str, result_dict = 'evaluation skipped: %s' % err, {}
+    if result_str is None:
+        result_str = 'evaluation skipped: no ground-truth annotations'
     logger.info(result_str)
     ret.update(result_dict)
     logger.info('Result is save to %s' % result_dir)

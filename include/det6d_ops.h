@@ -207,6 +207,48 @@ int det6d_make_slope(int n_points, float *points, int ld, int n_boxes, double *b
  * (core/pcdet/utils/box_utils.py:57-71). */
 int det6d_boxes9_corners(int n_boxes, const double *boxes9, double *corners, det6d_stream_t stream);
 
+/* ------------------------------------------------------------------ KITTI evaluator ------ */
+/* SURVEY.md §8 f3.  Reference: datasets/kitti/kitti_object_eval_python/{eval.py, rotate_iou.py} and the
+ * slopedkitti copy.  Frames are laid out ragged: dt_off / gt_off / dc_off (n_frames + 1, int32) index the
+ * concatenated detections / ground truths / DontCare boxes, pair_off (n_frames + 1, int64) the per-frame
+ * (n_dt x n_gt) row-major overlap blocks.  All arrays are device memory; boxes are float64 (float32
+ * detections converted exactly), `dt_f32` != 0 reproduces the float32 typing numba / NumPy apply to them.
+ *
+ * det6d_eval_overlaps: overlaps[pair_off[f] + j * n_gt + i] for detection j, ground truth i of frame f.
+ *   metric 0  image_box_overlap (eval.py:78-113), boxes (.,4) [x1,y1,x2,y2]
+ *   metric 1  bev_box_overlap = rotate_iou_gpu_eval (eval.py:116-118, rotate_iou.py), boxes (.,5) [x,z,l,w,ry]
+ *   metric 2  d3_box_overlap (eval.py:121-155), boxes (.,7) camera [x,y,z,l,h,w,ry]
+ *   metric 3  d9_box_matching_score, score_type 0 (slopedkitti eval.py:159-193), boxes (.,9) [loc,dims,yaw,pitch,roll] */
+int det6d_eval_overlaps(int metric, int n_frames, const int *dt_off, const int *gt_off, const int64_t *pair_off,
+                        int64_t n_pairs, const double *dt_boxes, const double *gt_boxes, int dt_f32,
+                        double *overlaps, det6d_stream_t stream);
+
+/* compute_statistics_jit (eval.py:160-275) for every frame (x every score threshold): the greedy
+ * ground-truth -> detection matching.  n_thresh == 0: pass A (compute_fp = False, thresh = 0): writes the
+ * scores of the true positives of frame f to tp_scores[gt_off[f] ..], their number to tp_count[f] and, if
+ * gt_of_tp != NULL, the matched ground-truth index per detection (-1 otherwise; slopedkitti eval.py:216,277).
+ * n_thresh > 0: pass B (fused_compute_statistics, eval.py:289-342): stats (n_frames, n_thresh, 4) =
+ * [tp, fp, fn, similarity] per frame and threshold; det6d_eval_reduce sums them over frames in frame order
+ * (similarity only where it is not -1) into pr (n_thresh, 4).
+ * workspace: max(1, total_dt * max(1, n_thresh)) bytes. */
+typedef struct det6d_eval_match_args {
+  int n_frames, n_thresh, metric, compute_aos, dt_f32;
+  double min_overlap;
+  const double *thresholds;                 /* (n_thresh) */
+  const int *dt_off, *gt_off, *dc_off;      /* (n_frames + 1) */
+  const int64_t *pair_off;                  /* (n_frames + 1) */
+  const double *overlaps;
+  const double *gt_alpha;                   /* (total_gt) */
+  const double *dt_bbox, *dt_alpha, *dt_score; /* (total_dt, 4), (total_dt), (total_dt) */
+  const int *ignored_gt, *ignored_dt;       /* 0 evaluate, 1 ignore, -1 other class (clean_data, eval.py:29-75) */
+  const double *dc_bbox;                    /* (total_dc, 4) */
+  unsigned char *workspace;
+  double *stats;                            /* pass B */
+  double *tp_scores; int *tp_count; int *gt_of_tp; /* pass A */
+} det6d_eval_match_args;
+int det6d_eval_match(const det6d_eval_match_args *args, det6d_stream_t stream);
+int det6d_eval_reduce(int n_frames, int n_thresh, const double *stats, double *pr, det6d_stream_t stream);
+
 /* ------------------------------------------------------------------ fused engine ops ----- */
 /* These have no 1:1 reference symbol; they implement the Python-level hot loop of
  * _PointnetSAModuleFSBase.forward (pointnet2_modules.py:462-494) and

@@ -970,3 +970,191 @@ ORACLE_API int det6d_oracle_boxes9_corners(int n_boxes, const double *boxes9, do
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * KITTI / SlopedKITTI evaluator: scalar mirrors of det6d_eval_overlaps / _match / _reduce.
+ *   image_box_overlap        core/pcdet/datasets/kitti/kitti_object_eval_python/eval.py:78-113
+ *   rotate_iou_gpu_eval      .../rotate_iou.py (via include/det6d_riou.h)
+ *   d3_box_overlap(_kernel)  eval.py:121-155
+ *   d9_box_matching_score    core/pcdet/datasets/slopedkitti/kitti_object_eval_python/eval.py:159-193
+ *   compute_statistics_jit   eval.py:160-275 ; fused_compute_statistics eval.py:289-342
+ * The loops are written the way the reference writes them (explicit assigned / ignored_threshold lists,
+ * the three-way if / elif of the matcher, delta list for the orientation similarity).
+ * ---------------------------------------------------------------------------------------- */
+#include "../include/det6d_riou.h"
+
+/* same layout as det6d_eval_match_args in include/det6d_ops.h (host pointers) */
+typedef struct det6d_eval_match_args {
+  int n_frames, n_thresh, metric, compute_aos, dt_f32;
+  double min_overlap;
+  const double *thresholds;
+  const int *dt_off, *gt_off, *dc_off;
+  const int64_t *pair_off;
+  const double *overlaps;
+  const double *gt_alpha;
+  const double *dt_bbox, *dt_alpha, *dt_score;
+  const int *ignored_gt, *ignored_dt;
+  const double *dc_bbox;
+  unsigned char *workspace;
+  double *stats;
+  double *tp_scores; int *tp_count; int *gt_of_tp;
+} det6d_eval_match_args;
+
+static double o_store(double v, int f32) { return f32 ? o_f32(v) : v; }
+
+static double o_image_overlap(const double *b, const double *q, int dt_f32, int criterion) {
+  const double q_area = (q[2] - q[0]) * (q[3] - q[1]);
+  const double iw = fmin(b[2], q[2]) - fmax(b[0], q[0]);
+  if (iw > 0) {
+    const double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]);
+    if (ih > 0) {
+      double b_area = (b[2] - b[0]) * (b[3] - b[1]);
+      if (dt_f32) b_area = o_f32(o_f32((float)b[2] - (float)b[0]) * o_f32((float)b[3] - (float)b[1]));
+      double ua = 1.0;
+      if (criterion == -1) ua = b_area + q_area - iw * ih;
+      else if (criterion == 0) ua = b_area;
+      else if (criterion == 1) ua = q_area;
+      return iw * ih / ua;
+    }
+  }
+  return 0.0;
+}
+
+ORACLE_API int det6d_oracle_eval_overlaps(int metric, int n_frames, const int *dt_off, const int *gt_off,
+                                          const int64_t *pair_off, int64_t n_pairs, const double *dt_boxes,
+                                          const double *gt_boxes, int dt_f32, double *overlaps) {
+  const int ncol = metric == 0 ? 4 : metric == 1 ? 5 : metric == 2 ? 7 : 9;
+  (void)n_pairs;
+  for (int f = 0; f < n_frames; ++f) {
+    const int n_dt = dt_off[f + 1] - dt_off[f], n_gt = gt_off[f + 1] - gt_off[f];
+    double *out = overlaps + pair_off[f];
+    for (int j = 0; j < n_dt; ++j)
+      for (int i = 0; i < n_gt; ++i) {
+        const double *b = dt_boxes + (size_t)(dt_off[f] + j) * ncol, *q = gt_boxes + (size_t)(gt_off[f] + i) * ncol;
+        double r = 0.0;
+        if (metric == 0) {
+          r = o_store(o_image_overlap(b, q, dt_f32, -1), dt_f32);
+        } else if (metric == 1) {
+          const float qb[5] = {(float)q[0], (float)q[1], (float)q[2], (float)q[3], (float)q[4]};
+          const float bb[5] = {(float)b[0], (float)b[1], (float)b[2], (float)b[3], (float)b[4]};
+          r = (double)d6_riou_eval(qb, bb, -1);
+        } else if (metric == 2) {
+          const float qb[5] = {(float)q[0], (float)q[2], (float)q[3], (float)q[5], (float)q[6]};
+          const float bb[5] = {(float)b[0], (float)b[2], (float)b[3], (float)b[5], (float)b[6]};
+          const double rinc = (double)d6_riou_eval(qb, bb, 2);
+          if (rinc > 0) {
+            const double b_top = dt_f32 ? o_f32((float)b[1] - (float)b[4]) : b[1] - b[4];
+            const double iw = fmin(b[1], q[1]) - fmax(b_top, q[1] - q[4]);
+            if (iw > 0) {
+              const double area1 = dt_f32 ? o_f32(o_f32((float)b[3] * (float)b[4]) * (float)b[5]) : b[3] * b[4] * b[5];
+              const double area2 = q[3] * q[4] * q[5];
+              const double inc = iw * rinc;
+              r = o_store(inc / (area1 + area2 - inc), dt_f32);
+            }
+          }
+        } else {
+          const double dx = b[0] - q[0], dy = b[1] - q[1], dz = b[2] - q[2];
+          const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+          r = o_store(2.0 - 2.0 * (1.0 / (1.0 + exp(-dist))), dt_f32);
+        }
+        out[(size_t)j * n_gt + i] = r;
+      }
+  }
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_eval_match(const det6d_eval_match_args *a) {
+  const int T = a->n_thresh > 0 ? a->n_thresh : 1;
+  const int compute_fp = a->n_thresh > 0;
+  const double NO_DETECTION = -10000000;
+  for (int f = 0; f < a->n_frames; ++f) {
+    const int d0 = a->dt_off[f], det_size = a->dt_off[f + 1] - d0;
+    const int g0 = a->gt_off[f], gt_size = a->gt_off[f + 1] - g0;
+    const double *overlaps = a->overlaps + a->pair_off[f];
+    char *assigned_detection = (char *)malloc((size_t)det_size + 1);
+    char *ignored_threshold = (char *)malloc((size_t)det_size + 1);
+    double *delta = (double *)malloc(sizeof(double) * (size_t)(gt_size + 1));
+    for (int t = 0; t < T; ++t) {
+      const double thresh = compute_fp ? a->thresholds[t] : 0.0;
+      for (int j = 0; j < det_size; ++j) {
+        assigned_detection[j] = 0;
+        ignored_threshold[j] = compute_fp && a->dt_score[d0 + j] < thresh;
+      }
+      if (!compute_fp && a->gt_of_tp) for (int j = 0; j < det_size; ++j) a->gt_of_tp[d0 + j] = -1;
+      int tp = 0, fp = 0, fn = 0, thresh_idx = 0, delta_idx = 0;
+      double similarity = 0;
+      for (int i = 0; i < gt_size; ++i) {
+        if (a->ignored_gt[g0 + i] == -1) continue;
+        int det_idx = -1, assigned_ignored_det = 0;
+        double valid_detection = NO_DETECTION, max_overlap = 0;
+        for (int j = 0; j < det_size; ++j) {
+          if (a->ignored_dt[d0 + j] == -1) continue;
+          if (assigned_detection[j]) continue;
+          if (ignored_threshold[j]) continue;
+          const double overlap = overlaps[(size_t)j * gt_size + i], dt_score = a->dt_score[d0 + j];
+          if (!compute_fp && overlap > a->min_overlap && dt_score > valid_detection) {
+            det_idx = j; valid_detection = dt_score;
+          } else if (compute_fp && overlap > a->min_overlap && (overlap > max_overlap || assigned_ignored_det) &&
+                     a->ignored_dt[d0 + j] == 0) {
+            max_overlap = overlap; det_idx = j; valid_detection = 1; assigned_ignored_det = 0;
+          } else if (compute_fp && overlap > a->min_overlap && valid_detection == NO_DETECTION &&
+                     a->ignored_dt[d0 + j] == 1) {
+            det_idx = j; valid_detection = 1; assigned_ignored_det = 1;
+          }
+        }
+        if (valid_detection == NO_DETECTION && a->ignored_gt[g0 + i] == 0) {
+          fn += 1;
+        } else if (valid_detection != NO_DETECTION && (a->ignored_gt[g0 + i] == 1 || a->ignored_dt[d0 + det_idx] == 1)) {
+          assigned_detection[det_idx] = 1;
+        } else if (valid_detection != NO_DETECTION) {
+          tp += 1;
+          if (!compute_fp) {
+            a->tp_scores[g0 + thresh_idx] = a->dt_score[d0 + det_idx];
+            if (a->gt_of_tp) a->gt_of_tp[d0 + det_idx] = i;
+          }
+          thresh_idx += 1;
+          if (a->compute_aos) delta[delta_idx++] = a->gt_alpha[g0 + i] - a->dt_alpha[d0 + det_idx];
+          assigned_detection[det_idx] = 1;
+        }
+      }
+      if (!compute_fp) { a->tp_count[f] = thresh_idx; continue; }
+      for (int j = 0; j < det_size; ++j)
+        if (!(assigned_detection[j] || a->ignored_dt[d0 + j] == -1 || a->ignored_dt[d0 + j] == 1 || ignored_threshold[j])) fp += 1;
+      int nstuff = 0;
+      if (a->metric == 0) {
+        for (int c = a->dc_off[f]; c < a->dc_off[f + 1]; ++c)
+          for (int j = 0; j < det_size; ++j) {
+            if (assigned_detection[j]) continue;
+            if (a->ignored_dt[d0 + j] == -1 || a->ignored_dt[d0 + j] == 1) continue;
+            if (ignored_threshold[j]) continue;
+            const double o = o_store(o_image_overlap(a->dt_bbox + (size_t)(d0 + j) * 4, a->dc_bbox + (size_t)c * 4, a->dt_f32, 0), a->dt_f32);
+            if (o > a->min_overlap) { assigned_detection[j] = 1; nstuff += 1; }
+          }
+      }
+      fp -= nstuff;
+      if (a->compute_aos) {
+        double sum = 0;
+        for (int k = 0; k < delta_idx; ++k) sum += (1.0 + cos(delta[k])) / 2.0;
+        similarity = (tp > 0 || fp > 0) ? sum : -1;
+      }
+      double *st = a->stats + ((size_t)f * T + t) * 4;
+      st[0] = tp; st[1] = fp; st[2] = fn; st[3] = similarity;
+    }
+    free(assigned_detection); free(ignored_threshold); free(delta);
+  }
+  return 0;
+}
+
+ORACLE_API int det6d_oracle_eval_reduce(int n_frames, int n_thresh, const double *stats, double *pr) {
+  for (int t = 0; t < n_thresh; ++t)
+    for (int c = 0; c < 4; ++c) {
+      double acc = 0;
+      for (int f = 0; f < n_frames; ++f) {
+        const double v = stats[((size_t)f * n_thresh + t) * 4 + c];
+        if (c == 3 && v == -1) continue;
+        acc += v;
+      }
+      pr[t * 4 + c] = acc;
+    }
+  return 0;
+}

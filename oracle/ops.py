@@ -422,3 +422,78 @@ def boxes9_corners(boxes9):
     out = np.empty((bx.shape[0], 8, 3), np.float64)
     lib().det6d_oracle_boxes9_corners(bx.shape[0], bx.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+# ---------------------------------------------------------------- KITTI evaluator (oracle backend)
+class _EvalMatchArgs(ctypes.Structure):
+    _fields_ = [("n_frames", ctypes.c_int), ("n_thresh", ctypes.c_int), ("metric", ctypes.c_int),
+                ("compute_aos", ctypes.c_int), ("dt_f32", ctypes.c_int), ("min_overlap", ctypes.c_double)] + \
+               [(n, ctypes.c_void_p) for n in ("thresholds", "dt_off", "gt_off", "dc_off", "pair_off", "overlaps", "gt_alpha",
+                                                "dt_bbox", "dt_alpha", "dt_score", "ignored_gt", "ignored_dt", "dc_bbox",
+                                                "workspace", "stats", "tp_scores", "tp_count", "gt_of_tp")]
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class EvalBackend(object):
+    """CPU-oracle counterpart of de6d_amd.ops.kitti_eval.DeviceEvalBackend (same methods, NumPy arrays)"""
+
+    def __init__(self, layout):
+        self.lay = layout
+        c = np.ascontiguousarray
+        self.dt_off, self.gt_off = c(layout.dt_off, np.int32), c(layout.gt_off, np.int32)
+        self.pair_off = c(layout.pair_off, np.int64)
+        self.gt_alpha, self.dt_alpha = c(layout.gt_alpha, np.float64), c(layout.dt_alpha, np.float64)
+        self.dt_score, self.dt_bbox = c(layout.dt_score, np.float64), c(layout.dt_boxes[0] if 0 in layout.dt_boxes else np.zeros((1, 4)), np.float64)
+        self._ov = {}
+
+    def overlaps(self, metric):
+        if metric not in self._ov:
+            n_pairs = int(self.pair_off[-1])
+            out = np.zeros(max(n_pairs, 1), np.float64)
+            dt, gt = (np.ascontiguousarray(b[metric], np.float64) for b in (self.lay.dt_boxes, self.lay.gt_boxes))
+            lib().det6d_oracle_eval_overlaps(metric, self.lay.n_frames, _vp(self.dt_off), _vp(self.gt_off), _vp(self.pair_off),
+                                             ctypes.c_int64(n_pairs), _vp(dt), _vp(gt), int(self.lay.dt_f32), _vp(out))
+            self._ov[metric] = out
+        return self._ov[metric]
+
+    def overlaps_host(self, metric):
+        return self.overlaps(metric)[:int(self.pair_off[-1])]
+
+    def _args(self, metric, ignored_gt, ignored_dt, dc_off, dc_bbox, min_overlap, n_thresh, compute_aos):
+        keep = [np.ascontiguousarray(ignored_gt, np.int32), np.ascontiguousarray(ignored_dt, np.int32),
+                np.ascontiguousarray(dc_off, np.int32),
+                np.ascontiguousarray(dc_bbox if len(dc_bbox) else np.zeros((1, 4)), np.float64), self.overlaps(metric)]
+        a = _EvalMatchArgs()
+        a.n_frames, a.n_thresh, a.metric, a.compute_aos, a.dt_f32 = self.lay.n_frames, n_thresh, metric, int(compute_aos), int(self.lay.dt_f32)
+        a.min_overlap = float(min_overlap)
+        for name, arr in (("dt_off", self.dt_off), ("gt_off", self.gt_off), ("dc_off", keep[2]), ("pair_off", self.pair_off),
+                          ("overlaps", keep[4]), ("gt_alpha", self.gt_alpha), ("dt_bbox", self.dt_bbox), ("dt_alpha", self.dt_alpha),
+                          ("dt_score", self.dt_score), ("ignored_gt", keep[0]), ("ignored_dt", keep[1]), ("dc_bbox", keep[3])):
+            setattr(a, name, arr.ctypes.data)
+        return a, keep
+
+    def pass_a(self, metric, ignored_gt, ignored_dt, dc_off, dc_bbox, min_overlap, want_gt_of_tp=False):
+        a, keep = self._args(metric, ignored_gt, ignored_dt, dc_off, dc_bbox, min_overlap, 0, False)
+        tp_scores = np.zeros(max(int(self.gt_off[-1]), 1), np.float64)
+        tp_count = np.zeros(max(self.lay.n_frames, 1), np.int32)
+        gt_of_tp = np.full(max(int(self.dt_off[-1]), 1), -1, np.int32)
+        a.tp_scores, a.tp_count = tp_scores.ctypes.data, tp_count.ctypes.data
+        a.gt_of_tp = gt_of_tp.ctypes.data if want_gt_of_tp else None
+        lib().det6d_oracle_eval_match(ctypes.byref(a))
+        return tp_scores[:int(self.gt_off[-1])], tp_count[:self.lay.n_frames], gt_of_tp[:int(self.dt_off[-1])] if want_gt_of_tp else None
+
+    def pass_b(self, metric, ignored_gt, ignored_dt, dc_off, dc_bbox, min_overlap, thresholds, compute_aos):
+        n_thresh = len(thresholds)
+        if n_thresh == 0:
+            return np.zeros((0, 4))
+        a, keep = self._args(metric, ignored_gt, ignored_dt, dc_off, dc_bbox, min_overlap, n_thresh, compute_aos)
+        thr = np.ascontiguousarray(thresholds, np.float64)
+        stats = np.zeros(max(self.lay.n_frames, 1) * n_thresh * 4, np.float64)
+        pr = np.zeros((n_thresh, 4), np.float64)
+        a.thresholds, a.stats = thr.ctypes.data, stats.ctypes.data
+        lib().det6d_oracle_eval_match(ctypes.byref(a))
+        lib().det6d_oracle_eval_reduce(self.lay.n_frames, n_thresh, _vp(stats), _vp(pr))
+        return pr

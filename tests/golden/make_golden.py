@@ -17,6 +17,11 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    KittiDataset / SlopedKittiDataSet.generate_prediction_dicts (+ box_utils, Calibration)
   slope.npz        SlopeAug: (boxes, points, seed) -> sloped boxes / points from the reference's OWN
                    augmentor_utils.random_global_make_slope (plain and smooth) and box_utils.boxes3d_to_corners_3d
+  kitti_eval.npz   KITTI / SlopedKITTI evaluator: synthetic label + detection annotations -> per-metric overlaps,
+                   precision / recall tables, mAP numbers and the printed report of the reference's OWN
+                   eval.py (both copies) executed as plain Python (numba.jit stubbed to the identity; the
+                   numba.cuda launch of rotate_iou_gpu_eval replaced by a loop over the reference's own
+                   devRotateIoUEval device function)
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -115,8 +120,8 @@ def install_reference_stubs():
     mod("SharedArray")
     mod("easydict", EasyDict=EasyDict)
     ident = lambda *a, **k: (a[0] if a and callable(a[0]) and not k else (lambda f: f))  # noqa: E731
-    cuda = mod("numba.cuda", jit=ident)
-    mod("numba", jit=ident, cuda=cuda, njit=ident, prange=range)
+    cuda = mod("numba.cuda", jit=ident, local=types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype)))
+    mod("numba", jit=ident, cuda=cuda, njit=ident, prange=range, float32=np.float32, int32=np.int32)
     mod("skimage"); mod("skimage.io"); mod("skimage.transform")
 
     class _Any(types.ModuleType):
@@ -394,6 +399,105 @@ def gen_slope():
           [int((out['out_%d_points' % c] != out['in_%d_points' % c]).any(1).sum()) for c in range(4)])
 
 
+# ----------------------------------------------------------------------------- evaluator
+def eval_annos(n_frames=12, seed=4242):
+    """synthetic split: ground-truth annos (float64, as kitti_common loads them) and detection annos
+    (float32, as generate_prediction_dicts writes them) in camera coordinates"""
+    rng = np.random.default_rng(seed)
+    names = np.array(['Car', 'Pedestrian', 'Cyclist', 'Van', 'DontCare', 'Person_sitting'])
+    size = {'Car': (3.9, 1.5, 1.6), 'Van': (4.8, 2.0, 1.9), 'Pedestrian': (0.8, 1.75, 0.6), 'Cyclist': (1.8, 1.7, 0.6),
+            'Person_sitting': (0.8, 1.2, 0.6), 'DontCare': (-1, -1, -1)}
+    gts, dts = [], []
+    for f in range(n_frames):
+        k = int(rng.integers(0 if f == 3 else 3, 9))
+        nm = names[rng.choice(len(names), k, p=[0.45, 0.15, 0.12, 0.1, 0.1, 0.08])]
+        loc = np.stack([rng.uniform(-12, 12, k), rng.uniform(1.4, 1.9, k), rng.uniform(6, 45, k)], 1)
+        dims = np.array([size[n] for n in nm]).reshape(k, 3) * rng.uniform(0.9, 1.1, (k, 1))
+        ry = rng.uniform(-np.pi, np.pi, k)
+        h_img = 720.0 * dims[:, 1] / loc[:, 2]
+        u = 620 + 720 * loc[:, 0] / loc[:, 2]
+        v = 180 + 720 * (loc[:, 1] - dims[:, 1] / 2) / loc[:, 2]
+        w_img = h_img * rng.uniform(0.8, 2.0, k)
+        bbox = np.stack([u - w_img / 2, v - h_img / 2, u + w_img / 2, v + h_img / 2], 1)
+        gt = dict(name=nm, truncated=rng.choice([0.0, 0.1, 0.25, 0.6], k), occluded=rng.integers(0, 4, k),
+                  alpha=-np.arctan2(loc[:, 0], loc[:, 2]) + ry, bbox=bbox, dimensions=dims, location=loc, rotation_y=ry,
+                  pitch=np.where(rng.uniform(size=k) < 0.5, 0.0, -rng.uniform(0.17, 0.4, k)), roll=np.zeros(k),
+                  score=np.zeros(k))
+        dc = nm == 'DontCare'
+        gt['dimensions'][dc] = -1; gt['location'][dc] = -1000; gt['rotation_y'][dc] = -10; gt['alpha'][dc] = -10
+        gts.append(gt)
+        # detections: noisy copies of most real objects + a few false alarms
+        keep = (~dc) & (rng.uniform(size=k) < 0.85)
+        m, fa = int(keep.sum()), int(rng.integers(0, 4))
+        jit = lambda a, s: a + rng.normal(0, s, a.shape)   # noqa: E731
+        d_loc = np.concatenate([jit(loc[keep], 0.12), np.stack([rng.uniform(-12, 12, fa), rng.uniform(1.4, 1.9, fa), rng.uniform(6, 45, fa)], 1)])
+        d_dims = np.concatenate([dims[keep] * rng.uniform(0.93, 1.07, (m, 3)), np.tile(size['Car'], (fa, 1))])
+        d_ry = np.concatenate([jit(ry[keep], 0.08), rng.uniform(-np.pi, np.pi, fa)])
+        d_bbox = np.concatenate([jit(bbox[keep], 2.0), np.stack([rng.uniform(0, 900, fa), rng.uniform(100, 200, fa)], 1).repeat(2, 1)
+                                 + np.array([0, 0, 60, 45.0])])
+        d_name = np.concatenate([np.where(nm[keep] == 'Van', 'Car', np.where(nm[keep] == 'Person_sitting', 'Pedestrian', nm[keep])),
+                                 rng.choice(['Car', 'Pedestrian', 'Cyclist'], fa)])
+        if fa and dc.any():                                   # a false alarm sitting on a DontCare region
+            d_bbox[m] = bbox[dc][0] + np.array([1.0, 1.0, -1.0, -1.0]); d_name[m] = 'Car'
+        n_dt = m + fa
+        dt = dict(name=d_name, truncated=np.zeros(n_dt), occluded=np.zeros(n_dt),
+                  alpha=(-np.arctan2(d_loc[:, 0], d_loc[:, 2]) + d_ry).astype(np.float32), bbox=d_bbox.astype(np.float32),
+                  dimensions=d_dims.astype(np.float32), location=d_loc.astype(np.float32), rotation_y=d_ry.astype(np.float32),
+                  pitch=np.concatenate([jit(gt['pitch'][keep], 0.03), np.zeros(fa)]).astype(np.float32),
+                  roll=np.zeros(n_dt, np.float32),
+                  score=np.concatenate([rng.uniform(0.35, 1.0, m), rng.uniform(0.05, 0.6, fa)]).astype(np.float32))
+        dts.append(dt)
+    return gts, dts
+
+
+def gen_eval():
+    import copy
+    import importlib
+    install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    out = {}
+    gts, dts = eval_annos()
+    for tag, pkg in (('kitti', 'pcdet.datasets.kitti.kitti_object_eval_python'),
+                     ('sloped', 'pcdet.datasets.slopedkitti.kitti_object_eval_python')):
+        ev = importlib.import_module(pkg + '.eval')
+        riou = importlib.import_module(pkg + '.rotate_iou')
+
+        def rotate_iou_loop(boxes, query_boxes, criterion=-1, device_id=0, _r=riou):
+            # host half of rotate_iou_gpu_eval (rotate_iou.py:302-330) with the kernel launch replaced by a
+            # loop over the reference's own device function, same (query, box) argument order as :297-299
+            b32, q32 = boxes.astype(np.float32), query_boxes.astype(np.float32)
+            iou = np.zeros((b32.shape[0], q32.shape[0]), np.float32)
+            for n in range(b32.shape[0]):
+                for k in range(q32.shape[0]):
+                    iou[n, k] = _r.devRotateIoUEval(q32[k], b32[n], criterion)
+            return iou.astype(boxes.dtype)
+
+        ev.rotate_iou_gpu_eval = rotate_iou_loop
+        detail = {}
+        g, d = copy.deepcopy(gts), copy.deepcopy(dts)
+        fn = ev.get_official_eval_result if tag == 'kitti' else ev.get_slopedkitti_eval_result
+        text, ret = fn(g, d, ['Car', 'Pedestrian', 'Cyclist'], PR_detail_dict=detail)
+        out[tag + '_report'] = np.array(text)
+        out[tag + '_ret_keys'] = np.array(sorted(ret))
+        out[tag + '_ret_vals'] = np.array([ret[k] for k in sorted(ret)])
+        for key, val in detail.items():
+            out['%s_precision_%s' % (tag, key)] = val
+        for metric in range(3 if tag == 'kitti' else 4):
+            ov = ev.calculate_iou_partly(copy.deepcopy(dts), copy.deepcopy(gts), metric, 100)[0]
+            for f, block in enumerate(ov):
+                out['%s_overlap_m%d_f%d' % (tag, metric, f)] = np.asarray(block)
+        print(tag, 'report:\n' + text[:600])
+    for f, (g, d) in enumerate(zip(gts, dts)):
+        for key, val in g.items():
+            out['gt_%d_%s' % (f, key)] = np.asarray(val) if key != 'name' else np.asarray(val).astype('U16')
+        for key, val in d.items():
+            out['dt_%d_%s' % (f, key)] = np.asarray(val) if key != 'name' else np.asarray(val).astype('U16')
+    out['n_frames'] = np.int64(len(gts))
+    np.savez_compressed(os.path.join(HERE, "kitti_eval.npz"), **out)
+    print("kitti_eval.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
@@ -403,3 +507,4 @@ if __name__ == "__main__":
     gen_producer()
     gen_annos()
     gen_slope()
+    gen_eval()
