@@ -118,6 +118,50 @@ def input_producer_rate(cfg, batch, n_raw=120000):
             "frac": round(alg / sec / 8e12, 4)}
 
 
+def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
+    """raw frames -> annotations: det6d_prepare_points (f1) -> captured Det6D graph -> det6d_kitti_annos + one
+    D2H + host dictionaries (f2), `depth` batches in flight; raw frames resident in HBM like the headline run"""
+    from de6d_amd.ops import fused as F
+    from de6d_amd.pcdet.datasets import KittiDataset
+    from de6d_amd.pcdet.utils.calibration_kitti import Calibration
+    dc = cfg.DATA_CONFIG
+    rng = np.random.default_rng(78)
+    r, a = rng.gamma(2.0, 12.0, batch * n_raw), rng.uniform(-np.pi, np.pi, batch * n_raw)
+    raw = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(-1.2, 0.6, batch * n_raw), rng.uniform(0, 1, batch * n_raw)], 1)
+    raw = torch.from_numpy(raw.astype(np.float32)).cuda()
+    offsets = torch.arange(0, batch + 1, dtype=torch.int32, device='cuda') * n_raw
+    calib = Calibration({'P2': np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.22], [0, 0, 1, 0.0027]], np.float32),
+                         'R0': np.eye(3, dtype=np.float32),
+                         'Tr_velo2cam': np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)})
+    meta = {'calib': [calib] * batch, 'image_shape': np.tile(np.array([[375, 1242]], np.int32), (batch, 1)),
+            'frame_id': ['%06d' % i for i in range(batch)]}
+    runners = [GraphedDet6D(model, batch, n) for _ in range(depth)]
+    scratch = [(torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
+                torch.empty((batch,), dtype=torch.int32, device='cuda')) for _ in range(depth)]
+
+    def run(k):
+        inflight, n_annos = [], 0
+        for i in range(k):
+            rn, (ws, cnt) = runners[i % depth], scratch[i % depth]
+            if len(inflight) >= depth:
+                n_annos += len(KittiDataset.generate_prediction_dicts(meta, inflight.pop(0).finalize(), cfg.CLASS_NAMES))
+            with torch.cuda.stream(rn.stream):
+                F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n, seed=i, out=rn.points, workspace=ws, n_in=cnt)
+            inflight.append(rn.launch())
+        for rn in inflight:
+            n_annos += len(KittiDataset.generate_prediction_dicts(meta, rn.finalize(), cfg.CLASS_NAMES))
+        return n_annos
+
+    run(depth * 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"scenes_per_s": round(frames / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3), "batches_in_flight": depth,
+            "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
+
+
 def linear_roofline(model, points, batch, flops_per_scene):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel: the SA / head MLP
     GEMMs) measured live with HIP events on the launch stream over one step"""
@@ -159,6 +203,7 @@ def main():
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
+    ap.add_argument('--h2d', action='store_true', help='PCIe-inclusive variant: every step uploads its batch from pinned host memory (never the headline value)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -184,6 +229,7 @@ def main():
     with torch.no_grad():
         model({'batch_size': b, 'points': points})  # fold weights, load code objects
     torch.cuda.synchronize()
+    runners = None
     if args.no_graph:
         streams = [torch.cuda.Stream() for _ in range(depth)]
 
@@ -200,7 +246,8 @@ def main():
             return dets
     else:
         # one captured hipGraph per stream, all reading the same resident input batch
-        runners = [GraphedDet6D(model, b, n, points=points) for _ in range(depth)]
+        runners = [GraphedDet6D(model, b, n, points=None if args.h2d else points) for _ in range(depth)]
+        host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
 
         def run(steps):
             inflight, dets = [], 0
@@ -208,7 +255,7 @@ def main():
                 r = runners[i % depth]
                 if len(inflight) >= depth:
                     dets += sum(len(p['pred_scores']) for p in inflight.pop(0).finalize())
-                inflight.append(r.launch())
+                inflight.append(r.launch(host_batch))
             for r in inflight:
                 dets += sum(len(p['pred_scores']) for p in r.finalize())
             return dets
@@ -244,12 +291,15 @@ def main():
                                    "(3-layer FSMSG SA + 6-DoF vote head + rotated NMS), random-init seeded "
                                    "weights; BASELINE.json configs[1]" % (b, n),
                        "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n,
-                       "streams": depth, "hipgraph": not args.no_graph, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
+                       "streams": depth, "hipgraph": not args.no_graph, "input": "pinned host, H2D per step" if args.h2d else "resident in HBM", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, points, b, flops)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
             line["input_producer"] = input_producer_rate(cfg, b)
+            runners = None  # noqa: F841  (frees the 24 captured graphs before the pipeline leg builds its own)
+            torch.cuda.empty_cache()
+            line["pipeline"] = pipeline_rate(cfg, model, b, n)
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

@@ -210,16 +210,21 @@ def mlp_chain3(rows_pts, idx, ctr, cnt, layers, out, col0):
     return out
 
 
-def prepare_points(raw, offsets, point_cloud_range, num_points, seed, scene_ids=None, near_depth=40.0):
+def prepare_points(raw, offsets, point_cloud_range, num_points, seed, scene_ids=None, near_depth=40.0, out=None,
+                   workspace=None, n_in=None):
     """raw (total_raw, C) concatenated frames + offsets (B+1) int32 -> (points (B*N, 1+C), n_in_range (B))
-    range mask + sample_points + collate batch index in one launch (include/det6d_ops.h: input producer)"""
-    L.require_cuda(raw, offsets, scene_ids)
+    range mask + sample_points + collate batch index in one launch (include/det6d_ops.h: input producer).
+    `out` / `workspace` / `n_in` may be passed to reuse buffers (e.g. a captured graph's static input)."""
+    L.require_cuda(raw, offsets, scene_ids, out, workspace, n_in)
     total_raw, c = raw.shape
     b = offsets.numel() - 1
     dev = raw.device
-    ws = torch.empty((int(L.lib().det6d_prepare_points_workspace_bytes(b, total_raw)),), dtype=torch.uint8, device=dev)
-    out = torch.empty((b * num_points, 1 + c), dtype=torch.float32, device=dev)
-    n_in = torch.empty((b,), dtype=torch.int32, device=dev)
+    need = int(L.lib().det6d_prepare_points_workspace_bytes(b, total_raw))
+    ws = workspace if workspace is not None and workspace.numel() >= need else torch.empty((need,), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty((b * num_points, 1 + c), dtype=torch.float32, device=dev)
+    if n_in is None:
+        n_in = torch.empty((b,), dtype=torch.int32, device=dev)
     r = [float(v) for v in point_cloud_range]
     L.call("det6d_prepare_points", b, L.ptr(offsets), L.ptr(scene_ids), total_raw, c, L.ptr(raw), r[0], r[1], r[3], r[4],
            int(num_points), float(near_depth), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), L.ptr(ws), L.ptr(out),
