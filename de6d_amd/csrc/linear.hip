@@ -32,7 +32,14 @@ __device__ __forceinline__ float relu_act(float v, int act) { return act == 1 ? 
 // (occupancy drops from 3 to 2 waves/SIMD), s_setprio around the MFMAs 93.  A timing-only ablation
 // without global loads, LDS stores and barriers (pure ds_read + MFMA loop) reaches 112-115 TF: that
 // is what the chip sustains under this load (DVFS), so the shipped kernel sits at 83-95 % of it.
-template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// FAST: the steady-state slabs are fetched with buffer_load_dwordx4 from per-thread byte offsets computed once
+// (rows / columns outside the problem are clamped to offset 0: they only feed outputs that are never stored)
+// plus a scalar k offset, so the main loop carries no address arithmetic, compares or zero-fill moves.
+// On gfx950 the fp32 MFMA shares the VALU: every vector ALU instruction in the loop is ~5 cycles taken from
+// the matrix pipe (scripts/hiptests/mfma_valu_overlap.hip), and the predicated form had ~56 of them per slab.
+template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1, bool FAST = true>
 __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
   constexpr int NA = BM / 64;    // A rows per thread
@@ -94,6 +101,38 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
 
   float4 ra[NA][KU];
   float4 rb[NB4];
+
+  // ---- fast loader: byte offsets relative to g.a / g.w, valid for every full slab ----
+  uint32_t voff_a[NA][KU], voff_b[NB4];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+      voff_a[i][u] = arow[i] ? (uint32_t)((arow[i] - g.a) + 4 * akq + 16 * u) * 4u : 0u;
+#pragma unroll
+  for (int i = 0; i < NB4; ++i) {
+    const int f = tid + 256 * i;
+    const int c = colb + 4 * (f % B4_PER_ROW);
+    const bool ok = f < BK * B4_PER_ROW && c + 3 < g.ldw;
+    voff_b[i] = ok ? (uint32_t)((f / B4_PER_ROW) * g.ldw + c) * 4u : 0u;
+  }
+  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.a, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void *)g.w, 0, 0xffffffff, 0x00020000);
+  auto load_tile_fast = [&](int k0) {   // requires k0 > 0 and k0 + BK <= K
+    const int soff_a = k0 * 4, soff_b = k0 * g.ldw * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(srd_a, voff_a[i][u], soff_a, 0));
+        ra[i][u] = make_float4(v.x, v.y, v.z, v.w);
+      }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff_b[i], soff_b, 0));
+      rb[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
 
   auto load_tile = [&](int k0) {
 #pragma unroll
@@ -187,7 +226,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   load_tile(0);
   if (NBUF == 1) {
     int k0 = 0;
-    for (; k0 + BK <= K; k0 += BK) {
+    if (FAST) {   // steady state: the next slab is full, fetched by the predicate-free loader
+      for (; k0 + 2 * BK <= K; k0 += BK) {
+        store_tile(0);
+        __syncthreads();
+        load_tile_fast(k0 + BK);
+        compute(0);
+        __syncthreads();
+      }
+    }
+    for (; k0 + BK <= K; k0 += BK) {   // FAST: only the last full slab (its successor, if any, is the short one)
       store_tile(0);
       __syncthreads();
       if (k0 + BK < K) load_tile(k0 + BK);
@@ -297,11 +345,36 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   if (a->rows == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
   const int gm = det6d_divup(a->rows, 128);
+  // the buffer-load fast path addresses A and W with 32-bit byte offsets
+  const size_t a_rows = a->mode == DET6D_A_GROUPED ? (size_t)(a->rows / (a->m * a->ns)) * a->n : (size_t)a->rows;
+  const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull;
+  static const bool no_fast = getenv("DET6D_LINEAR_NO_FAST") != nullptr;
+  if (!fits32 || no_fast) {   // same tiles, plain predicated loader
+    if (a->ncols > 64) {
+      if (gm * det6d_divup(a->ncols, 128) < 256)
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+                           dim3(256), 0, s, *a);
+      else if (a->ncols <= 512 && a->k <= 256)
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, false>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+      else
+        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, false>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+    } else if (a->ncols > 32) {
+      if (gm < 128)
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
+      else
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, false>), dim3(gm), dim3(256), 0, s, *a);
+    } else {
+      hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1, 16, 1, false>), dim3(gm), dim3(256), 0, s, *a);
+    }
+    return det6d_check_launch("det6d_linear");
+  }
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
-    // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles
+    // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles.  These
+    // launches are latency-bound (one wave per SIMD): the buffer-load fast path measured 5-9 % SLOWER
+    // there, so they keep the plain loader (FAST = false).
     if (gm * det6d_divup(a->ncols, 128) < 256)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                          dim3(256), 0, s, *a);
     else if (a->ncols <= 512 && a->k <= 256)
       // measured on MI355X (scripts/gpu_linear_variants.py): with short K loops the 128x64 tile's higher
@@ -311,7 +384,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
     if (gm < 128)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm), dim3(256), 0, s, *a);
   } else {

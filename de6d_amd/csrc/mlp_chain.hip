@@ -18,6 +18,7 @@
 // Arithmetic is identical to three det6d_linear calls: every output is one ascending-k fmaf chain,
 // + shift, ReLU; masked max over the nsample rows.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -185,6 +186,150 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident variant for the widths Det6D's first SA layer uses ([4->16->16->32], [4->32->32->64]).
+//
+// Layers 1 and 2 are computed TRANSPOSED, D = W^T X^T: the weight fragment is the MFMA A operand (channel on
+// lane&31), the activations the B operand (row on lane&31).  The accumulator then holds, per lane, 16
+// CHANNELS of ONE row — and after ReLU that is, up to a lane-half exchange, exactly the B (or A) operand
+// fragment of the next layer: `v_permlane32_swap` on register pairs turns {half0: ch 8G+0..3, half1: ch
+// 8G+4..7} into per-step fragments {half0: ch 2s, half1: ch 2s+1}.  No LDS round trip, no barrier, no
+// transposing stores; all weight fragments of the three layers stay in VGPRs (52 for the wide group).
+// The folded-BN shift of layers 1-2 rides on one extra MFMA step (a = shift on the k0 half, b = 1):
+// fma(shift, 1, acc) == acc + shift exactly, added last like the oracle does.  Layer 3 runs in the normal
+// orientation (same fragments, operands swapped back) so that the max over the nsample rows is the cheap
+// in-register / one-shuffle epilogue and the store is coalesced.
+// Every output is still ONE ascending-k fma chain: bit-identical to det6d_linear x 3.
+// max(v, 0) in ONE v_max_f32 (the C form costs a canonicalising v_max first); inputs are never NaN
+__device__ __forceinline__ float relu_fast(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
+  constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
+  constexpr int S2 = C1 / 2, S3 = C2 / 2, NT3 = C3 / 32;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+
+  // weight fragments: lane (channel / column = l31, k = 2s + kh); one more step per transposed layer for the shift
+  float wf1[S1 + 1], wf2[S2 + 1], wf3[NT3][S3];
+#pragma unroll
+  for (int s = 0; s < S1; ++s) wf1[s] = l31 < C1 ? g.w1[(size_t)(2 * s + kh) * g.ldw1 + l31] : 0.f;
+  wf1[S1] = (kh == 0 && l31 < C1) ? g.s1[l31] : 0.f;
+#pragma unroll
+  for (int s = 0; s < S2; ++s) wf2[s] = l31 < C2 ? g.w2[(size_t)(2 * s + kh) * g.ldw2 + l31] : 0.f;
+  wf2[S2] = (kh == 0 && l31 < C2) ? g.s2[l31] : 0.f;
+#pragma unroll
+  for (int j = 0; j < NT3; ++j)
+#pragma unroll
+    for (int s = 0; s < S3; ++s) wf3[j][s] = g.w3[(size_t)(2 * s + kh) * g.ldw3 + 32 * j + l31];
+  float sh3[NT3];
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) sh3[j] = g.s3[32 * j + l31];
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+
+  const int ntiles = g.rows / 32;
+  int tile = wave_global;
+  if (tile >= ntiles) return;
+  // software pipeline: the neighbour index of the tile after next and the point row of the next tile are in
+  // flight while this tile computes (index -> row is a dependent pair of loads)
+  struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; };
+  auto fetch = [&](int t, int p) {
+    TileIn in;
+    const int cj = (t * 32 + l31) / g.ns;
+    in.row = *reinterpret_cast<const float4 *>(g.a + ((size_t)(cj / g.m) * g.n + p) * 4);
+    const float *c = g.ctr + (size_t)cj * g.ldctr;
+    in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
+    in.cnt0 = g.ns == 32 ? g.cnt[t] : g.cnt[2 * t];
+    in.cnt1 = g.ns == 32 ? 0 : g.cnt[2 * t + 1];
+    return in;
+  };
+  TileIn nxt = fetch(tile, g.idx[tile * 32 + l31]);
+  int p_next = tile + n_waves < ntiles ? g.idx[(tile + n_waves) * 32 + l31] : 0;
+  for (; tile < ntiles; tile += n_waves) {
+    const TileIn cur = nxt;
+    if (tile + n_waves < ntiles) {
+      nxt = fetch(tile + n_waves, p_next);
+      if (tile + 2 * n_waves < ntiles) p_next = g.idx[(tile + 2 * n_waves) * 32 + l31];
+    }
+    const float4 v0 = cur.row;
+    const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
+    const float x0 = v0.x - cx, x1 = v0.y - cy, x2 = v0.z - cz, x3 = v0.w;
+
+    // ---- layer 1 (transposed): acc[e] = channel (e&3) + 8*(e>>2) + 4*kh of row l31 ----
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[0], kh ? x1 : x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[1], kh ? x3 : x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[2], one_k0, acc, 0, 0, 0);
+    float frag[16];   // frag[s] = activation fragment of k-step s: {half0: channel 2s, half1: channel 2s + 1}
+    auto to_fragments = [&](const f32x16 &a, int nreg) {
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        if (4 * G >= nreg) break;
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = relu_fast(a[4 * G + e]);
+        // inline asm: this compiler drops the SECOND result of __builtin_amdgcn_permlane32_swap (seen in the ISA:
+        // the source register is reused right after the swap).  a = [a.lo | b.lo], b = [a.hi | b.hi] afterwards.
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+        frag[4 * G + 0] = t[0];   // channels 8G + 0, 1
+        frag[4 * G + 1] = t[2];   // channels 8G + 2, 3
+        frag[4 * G + 2] = t[1];   // channels 8G + 4, 5
+        frag[4 * G + 3] = t[3];   // channels 8G + 6, 7
+      }
+    };
+    to_fragments(acc, S2);
+    // ---- layer 2 (transposed) ----
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < S2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf2[s], frag[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf2[S2], one_k0, acc, 0, 0, 0);
+    to_fragments(acc, S3);
+    // ---- layer 3 (rows in the registers again), shift + ReLU + mask + max over the nsample rows ----
+#pragma unroll
+    for (int j = 0; j < NT3; ++j) {
+      f32x16 o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < S3; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s], wf3[j][s], o, 0, 0, 0);
+      const int col = 32 * j + l31;
+      float q[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float mx = relu_fast(o[4 * qq] + sh3[j]);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+          const float v = relu_fast(o[4 * qq + e] + sh3[j]);
+          mx = v > mx ? v : mx;
+        }
+        const float other = __shfl_xor(mx, 32);
+        q[qq] = other > mx ? other : mx;
+      }
+      if (g.ns == 32) {
+        float mx = q[0];
+        mx = q[1] > mx ? q[1] : mx; mx = q[2] > mx ? q[2] : mx; mx = q[3] > mx ? q[3] : mx;
+        if (kh == 0) g.y[(size_t)tile * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? mx : 0.f;
+      } else {
+        const float m0 = q[1] > q[0] ? q[1] : q[0];
+        const float m1 = q[3] > q[2] ? q[3] : q[2];
+        if (kh == 0) {
+          g.y[(size_t)(2 * tile) * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? m0 : 0.f;
+          g.y[(size_t)(2 * tile + 1) * g.ldy + g.col0 + col] = (cur.cnt1 > 0) ? m1 : 0.f;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
@@ -209,6 +354,16 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   const int ntiles = rows / 32;
   int blocks = det6d_divup(ntiles, kChainWaves);
   if (blocks > 256 * 6) blocks = 256 * 6;     // persistent-ish: amortise the weight staging over many tiles
-  hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(64 * kChainWaves), 0, (hipStream_t)stream, g);
+  static const bool use_lds = getenv("DET6D_CHAIN_LDS") != nullptr;
+  // register kernel: a grid of exactly one residency round (256 CUs x 4 SIMDs x 4 waves) so that every wave
+  // walks the same number of tiles (1536 blocks left half the chip idle in the second round)
+  static const int reg_blocks_env = getenv("DET6D_CHAIN_BLOCKS") ? atoi(getenv("DET6D_CHAIN_BLOCKS")) : 1024;
+  const int reg_blocks = blocks < reg_blocks_env ? blocks : reg_blocks_env;
+  if (!use_lds && lda == 4 && c1 == 16 && c2 == 16 && c3 == 32)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else if (!use_lds && lda == 4 && c1 == 32 && c2 == 32 && c3 == 64)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<32, 32, 64>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(64 * kChainWaves), 0, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_chain3");
 }

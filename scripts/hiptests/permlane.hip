@@ -1,0 +1,18 @@
+// what v_permlane32_swap does, printed from the device (semantics check for mlp_chain.hip)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+__global__ void k(unsigned *out) {
+  const unsigned a = 100 + threadIdx.x, b = 200 + threadIdx.x;
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  out[threadIdx.x] = r[0];
+  out[64 + threadIdx.x] = r[1];
+}
+int main() {
+  unsigned *d, h[128];
+  hipMalloc(&d, sizeof(h));
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+  hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  printf("r0: lane0 %u lane31 %u lane32 %u lane63 %u\n", h[0], h[31], h[32], h[63]);
+  printf("r1: lane0 %u lane31 %u lane32 %u lane63 %u\n", h[64], h[95], h[96], h[127]);
+  return 0;
+}
