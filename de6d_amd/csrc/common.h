@@ -82,6 +82,19 @@ __device__ __forceinline__ float d6_vmin(float a, float b) {
   return r;
 }
 
+// one-instruction max / ReLU (the C forms cost a canonicalising v_max or a compare + select first); no NaN inputs.
+// On gfx950 every VALU instruction beside fp32 MFMAs is matrix time lost, hence these.
+__device__ __forceinline__ float d6_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float d6_relu(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 __device__ __forceinline__ float d6_readlane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

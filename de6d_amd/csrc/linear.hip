@@ -39,8 +39,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // plus a scalar k offset, so the main loop carries no address arithmetic, compares or zero-fill moves.
 // On gfx950 the fp32 MFMA shares the VALU: every vector ALU instruction in the loop is ~5 cycles taken from
 // the matrix pipe (scripts/hiptests/mfma_valu_overlap.hip), and the predicated form had ~56 of them per slab.
-template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1, bool FAST = true>
+template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1, int FASTLVL = 2>
 __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
+  constexpr bool FAST = FASTLVL >= 2;      // predicate-free buffer_load main loop
+  constexpr bool FAST_EPI = FASTLVL >= 1;  // predicate-free buffer_store epilogue on interior tiles (32-bit offsets)
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
   constexpr int NA = BM / 64;    // A rows per thread
   constexpr int KU = BK / 16;    // k-quads per row per thread
@@ -223,7 +225,30 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
     for (int ks = 0; ks < nks; ++ks) kstep(As_all, Bs_all, ks);
   };
 
-  load_tile(0);
+  if (FAST && BK <= K) {
+    // slab 0 through the fast loader too; grouped_xyz -= new_xyz touches the first float4 of each row only
+    const int soff0 = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(srd_a, voff_a[i][u], soff0, 0));
+        ra[i][u] = make_float4(v.x, v.y, v.z, v.w);
+      }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff_b[i], soff0, 0));
+      rb[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    if (g.mode == DET6D_A_GROUPED && akq == 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        ra[i][0].x = ra[i][0].x - csub[i][0]; ra[i][0].y = ra[i][0].y - csub[i][1]; ra[i][0].z = ra[i][0].z - csub[i][2];
+      }
+    }
+  } else {
+    load_tile(0);
+  }
   if (NBUF == 1) {
     int k0 = 0;
     if (FAST) {   // steady state: the next slab is full, fetched by the predicate-free loader
@@ -262,6 +287,34 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
   }
 
   // ---- epilogue ----
+  // interior tiles of plain (non-pooled) layers: no bound predicates, no 64-bit address arithmetic — one
+  // per-lane byte offset per 32x32 tile, the row of each accumulator register as a scalar offset
+  if (FAST_EPI && g.pool == 0 && row0 + BM <= R && colb + BN <= N) {
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)g.y, 0, 0xffffffff, 0x00020000);
+    const int ldy4 = g.ldy * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colb + wn * 32 * TN + 32 * j + l31;
+      const float sh = g.shift ? g.shift[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rbase = row0 + wm * 32 * TM + 32 * i;
+        const uint32_t voff = (uint32_t)((rbase + 4 * kh) * g.ldy + g.col0 + col) * 4u;
+        if (g.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d6_relu(acc[i][j][e] + sh)), srd_y, voff,
+                                                  ((e & 3) + 8 * (e >> 2)) * ldy4, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][e] + sh), srd_y, voff,
+                                                  ((e & 3) + 8 * (e >> 2)) * ldy4, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = colb + wn * 32 * TN + 32 * j + l31;
@@ -277,30 +330,25 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
           if (cok && row < R) g.y[(size_t)row * g.ldy + g.col0 + col] = relu_act(acc[i][j][e] + sh, g.act);
         }
       } else {
-        // rows of a tile: (e&3) + 8*(e>>2) + 4*kh  -> 8-row bundle q = e>>2 spans both lane halves
+        // rows of a tile: (e&3) + 8*(e>>2) + 4*kh  -> 8-row bundle q = e>>2 spans both lane halves.
+        // x -> act(x + shift) is monotone, so the max over the rows is taken on the raw accumulators and
+        // shift / ReLU are applied to the pooled value only (identical result, a third of the vector ops).
         float q[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-          float m = relu_act(acc[i][j][4 * qq] + sh, g.act);
-#pragma unroll
-          for (int e = 1; e < 4; ++e) {
-            const float v = relu_act(acc[i][j][4 * qq + e] + sh, g.act);
-            m = v > m ? v : m;
-          }
-          const float o = __shfl_xor(m, 32);
-          q[qq] = o > m ? o : m;
+          float m = d6_vmax(d6_vmax(acc[i][j][4 * qq], acc[i][j][4 * qq + 1]), d6_vmax(acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]));
+          q[qq] = d6_vmax(m, __shfl_xor(m, 32));
         }
         if (g.pool == 32) {
-          float m = q[0];
-          m = q[1] > m ? q[1] : m; m = q[2] > m ? q[2] : m; m = q[3] > m ? q[3] : m;
+          const float m = relu_act(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh, g.act);
           const int grp = rbase / 32;
           if (cok && kh == 0 && rbase < R) {
             const bool live = g.cnt ? g.cnt[grp] > 0 : true;
             g.y[(size_t)grp * g.ldy + g.col0 + col] = live ? m : 0.f;
           }
         } else if (g.pool == 16) {
-          const float m0 = q[1] > q[0] ? q[1] : q[0];
-          const float m1 = q[3] > q[2] ? q[3] : q[2];
+          const float m0 = relu_act(d6_vmax(q[0], q[1]) + sh, g.act);
+          const float m1 = relu_act(d6_vmax(q[2], q[3]) + sh, g.act);
           const int grp = rbase / 16;
           if (cok && kh == 0) {
             if (rbase < R) {
@@ -319,7 +367,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) 
             for (int qq = 0; qq < 4; ++qq)
               if (rbase + 8 * qq < R) {
                 const bool live = g.cnt ? g.cnt[grp + qq] > 0 : true;
-                g.y[(size_t)(grp + qq) * g.ldy + g.col0 + col] = live ? q[qq] : 0.f;
+                g.y[(size_t)(grp + qq) * g.ldy + g.col0 + col] = live ? relu_act(q[qq] + sh, g.act) : 0.f;
               }
           }
         }
@@ -347,24 +395,25 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   const int gm = det6d_divup(a->rows, 128);
   // the buffer-load fast path addresses A and W with 32-bit byte offsets
   const size_t a_rows = a->mode == DET6D_A_GROUPED ? (size_t)(a->rows / (a->m * a->ns)) * a->n : (size_t)a->rows;
-  const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull;
+  const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull &&
+                      (size_t)a->rows * a->ldy * 4 < 0xfff00000ull;
   static const bool no_fast = getenv("DET6D_LINEAR_NO_FAST") != nullptr;
   if (!fits32 || no_fast) {   // same tiles, plain predicated loader
     if (a->ncols > 64) {
       if (gm * det6d_divup(a->ncols, 128) < 256)
-        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 0>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                            dim3(256), 0, s, *a);
       else if (a->ncols <= 512 && a->k <= 256)
-        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, false>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
       else
-        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, false>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, 0>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     } else if (a->ncols > 32) {
       if (gm < 128)
-        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 0>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
       else
-        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, false>), dim3(gm), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm), dim3(256), 0, s, *a);
     } else {
-      hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1, 16, 1, false>), dim3(gm), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1, 16, 1, 0>), dim3(gm), dim3(256), 0, s, *a);
     }
     return det6d_check_launch("det6d_linear");
   }
@@ -374,7 +423,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     // launches are latency-bound (one wave per SIMD): the buffer-load fast path measured 5-9 % SLOWER
     // there, so they keep the plain loader (FAST = false).
     if (gm * det6d_divup(a->ncols, 128) < 256)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                          dim3(256), 0, s, *a);
     else if (a->ncols <= 512 && a->k <= 256)
       // measured on MI355X (scripts/gpu_linear_variants.py): with short K loops the 128x64 tile's higher
@@ -384,7 +433,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
     if (gm < 128)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, false>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm), dim3(256), 0, s, *a);
   } else {

@@ -200,13 +200,6 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
 // orientation (same fragments, operands swapped back) so that the max over the nsample rows is the cheap
 // in-register / one-shuffle epilogue and the store is coalesced.
 // Every output is still ONE ascending-k fma chain: bit-identical to det6d_linear x 3.
-// max(v, 0) in ONE v_max_f32 (the C form costs a canonicalising v_max first); inputs are never NaN
-__device__ __forceinline__ float relu_fast(float v) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-  return r;
-}
-
 template <int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
@@ -274,7 +267,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
         if (4 * G >= nreg) break;
         float t[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = relu_fast(a[4 * G + e]);
+        for (int e = 0; e < 4; ++e) t[e] = d6_relu(a[4 * G + e]);
         // inline asm: this compiler drops the SECOND result of __builtin_amdgcn_permlane32_swap (seen in the ISA:
         // the source register is reused right after the swap).  a = [a.lo | b.lo], b = [a.hi | b.hi] afterwards.
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
@@ -302,25 +295,19 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
 #pragma unroll
       for (int s = 0; s < S3; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s], wf3[j][s], o, 0, 0, 0);
       const int col = 32 * j + l31;
+      // max over the rows on the raw accumulators, shift + ReLU on the pooled value (monotone: same result)
       float q[4];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        float mx = relu_fast(o[4 * qq] + sh3[j]);
-#pragma unroll
-        for (int e = 1; e < 4; ++e) {
-          const float v = relu_fast(o[4 * qq + e] + sh3[j]);
-          mx = v > mx ? v : mx;
-        }
-        const float other = __shfl_xor(mx, 32);
-        q[qq] = other > mx ? other : mx;
+        const float mq = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
+        q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
       }
       if (g.ns == 32) {
-        float mx = q[0];
-        mx = q[1] > mx ? q[1] : mx; mx = q[2] > mx ? q[2] : mx; mx = q[3] > mx ? q[3] : mx;
+        const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
         if (kh == 0) g.y[(size_t)tile * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? mx : 0.f;
       } else {
-        const float m0 = q[1] > q[0] ? q[1] : q[0];
-        const float m1 = q[3] > q[2] ? q[3] : q[2];
+        const float m0 = d6_relu(d6_vmax(q[0], q[1]) + sh3[j]);
+        const float m1 = d6_relu(d6_vmax(q[2], q[3]) + sh3[j]);
         if (kh == 0) {
           g.y[(size_t)(2 * tile) * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? m0 : 0.f;
           g.y[(size_t)(2 * tile + 1) * g.ldy + g.col0 + col] = (cur.cnt1 > 0) ? m1 : 0.f;
