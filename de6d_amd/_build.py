@@ -17,7 +17,10 @@ HEADERS = [os.path.join(CSRC, "common.h"),
            os.path.join(HERE, "..", "include", "det6d_riou.h")]
 # -ffp-contract=off + correctly rounded divide: the arithmetic contract shared with the oracle
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wno-unused-value"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt",
+         # MFMA accumulators in architectural VGPRs: no v_accvgpr_read before the epilogue / the next layer
+         # (vector-ALU instructions are matrix time on gfx950 for fp32 MFMA)
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-fvisibility=hidden", "-Wno-unused-value"]
 
 
 def _hipcc():

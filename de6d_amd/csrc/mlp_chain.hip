@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
 // orientation (same fragments, operands swapped back) so that the max over the nsample rows is the cheap
 // in-register / one-shuffle epilogue and the store is coalesced.
 // Every output is still ONE ascending-k fma chain: bit-identical to det6d_linear x 3.
-template <int C1, int C2, int C3>
+template <int C1, int C2, int C3, int NS>
 __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
   constexpr int S2 = C1 / 2, S3 = C2 / 2, NT3 = C3 / 32;
@@ -226,25 +226,45 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   const float one_k0 = kh == 0 ? 1.f : 0.f;
 
   const int ntiles = g.rows / 32;
-  int tile = wave_global;
+  // the tile index is wave-uniform: kept in SGPRs so that the batch index (a division by m) is scalar work
+  int tile = __builtin_amdgcn_readfirstlane(wave_global);
   if (tile >= ntiles) return;
   // software pipeline: the neighbour index of the tile after next and the point row of the next tile are in
   // flight while this tile computes (index -> row is a dependent pair of loads)
   struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; };
-  auto fetch = [&](int t, int p) {
+  auto fetch = [&](int t, int p) {   // t wave-uniform; for NS == 16 the two centres of a tile share the batch (m even)
     TileIn in;
-    const int cj = (t * 32 + l31) / g.ns;
-    in.row = *reinterpret_cast<const float4 *>(g.a + ((size_t)(cj / g.m) * g.n + p) * 4);
+    const int c0 = NS == 32 ? t : 2 * t;             // first centre of the tile (scalar)
+    const int bi = c0 / g.m;                         // scalar division
+    const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
+    in.row = *reinterpret_cast<const float4 *>(g.a + ((size_t)bi * g.n + p) * 4);
     const float *c = g.ctr + (size_t)cj * g.ldctr;
     in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
-    in.cnt0 = g.ns == 32 ? g.cnt[t] : g.cnt[2 * t];
-    in.cnt1 = g.ns == 32 ? 0 : g.cnt[2 * t + 1];
+    in.cnt0 = g.cnt[c0];
+    in.cnt1 = NS == 32 ? 0 : g.cnt[c0 + 1];
     return in;
   };
   TileIn nxt = fetch(tile, g.idx[tile * 32 + l31]);
   int p_next = tile + n_waves < ntiles ? g.idx[(tile + n_waves) * 32 + l31] : 0;
+  // results are stored one iteration late, BEFORE the next prefetch is issued: the wait for the prefetched
+  // inputs at the top of an iteration then never waits for this tile's stores (vmcnt counts in order)
+  float pend[NT3][2];
+  int pend_tile = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT3; ++j) {
+      const int col = 32 * j + l31;
+      if (NS == 32) {
+        g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
+      } else {
+        g.y[(size_t)(2 * pend_tile) * g.ldy + g.col0 + col] = pend[j][0];
+        g.y[(size_t)(2 * pend_tile + 1) * g.ldy + g.col0 + col] = pend[j][1];
+      }
+    }
+  };
   for (; tile < ntiles; tile += n_waves) {
     const TileIn cur = nxt;
+    if (pend_tile >= 0) flush();
     if (tile + n_waves < ntiles) {
       nxt = fetch(tile + n_waves, p_next);
       if (tile + 2 * n_waves < ntiles) p_next = g.idx[(tile + 2 * n_waves) * 32 + l31];
@@ -302,19 +322,19 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
         const float mq = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
         q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
       }
-      if (g.ns == 32) {
+      if (NS == 32) {
         const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
-        if (kh == 0) g.y[(size_t)tile * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? mx : 0.f;
+        pend[j][0] = (cur.cnt0 > 0) ? mx : 0.f;   // both lane halves hold the pooled value: all 64 lanes store it
       } else {
         const float m0 = d6_relu(d6_vmax(q[0], q[1]) + sh3[j]);
         const float m1 = d6_relu(d6_vmax(q[2], q[3]) + sh3[j]);
-        if (kh == 0) {
-          g.y[(size_t)(2 * tile) * g.ldy + g.col0 + col] = (cur.cnt0 > 0) ? m0 : 0.f;
-          g.y[(size_t)(2 * tile + 1) * g.ldy + g.col0 + col] = (cur.cnt1 > 0) ? m1 : 0.f;
-        }
+        pend[j][0] = (cur.cnt0 > 0) ? m0 : 0.f;
+        pend[j][1] = (cur.cnt1 > 0) ? m1 : 0.f;
       }
     }
+    pend_tile = tile;
   }
+  flush();
 }
 
 }  // namespace
@@ -341,15 +361,20 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   const int ntiles = rows / 32;
   int blocks = det6d_divup(ntiles, kChainWaves);
   if (blocks > 256 * 6) blocks = 256 * 6;     // persistent-ish: amortise the weight staging over many tiles
-  static const bool use_lds = getenv("DET6D_CHAIN_LDS") != nullptr;
+  static const bool use_lds_env = getenv("DET6D_CHAIN_LDS") != nullptr;
+  const bool use_lds = use_lds_env || (ns == 16 && (m & 1));   // the register kernel pairs two centres of ONE batch per tile
   // register kernel: a grid of exactly one residency round (256 CUs x 4 SIMDs x 4 waves) so that every wave
   // walks the same number of tiles (1536 blocks left half the chip idle in the second round)
   static const int reg_blocks_env = getenv("DET6D_CHAIN_BLOCKS") ? atoi(getenv("DET6D_CHAIN_BLOCKS")) : 1024;
   const int reg_blocks = blocks < reg_blocks_env ? blocks : reg_blocks_env;
-  if (!use_lds && lda == 4 && c1 == 16 && c2 == 16 && c3 == 32)
-    hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
-  else if (!use_lds && lda == 4 && c1 == 32 && c2 == 32 && c3 == 64)
-    hipLaunchKernelGGL((mlp_chain_reg_kernel<32, 32, 64>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  if (!use_lds && lda == 4 && c1 == 16 && c2 == 16 && c3 == 32 && ns == 16)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32, 16>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else if (!use_lds && lda == 4 && c1 == 16 && c2 == 16 && c3 == 32 && ns == 32)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32, 32>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else if (!use_lds && lda == 4 && c1 == 32 && c2 == 32 && c3 == 64 && ns == 16)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<32, 32, 64, 16>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else if (!use_lds && lda == 4 && c1 == 32 && c2 == 32 && c3 == 64 && ns == 32)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<32, 32, 64, 32>), dim3(reg_blocks), dim3(256), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(64 * kChainWaves), 0, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_chain3");
