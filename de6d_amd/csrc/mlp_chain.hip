@@ -337,6 +337,156 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   flush();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide register chain: the same transposed-accumulator scheme for the second SA layer's groups
+// ([68->64->64->128], [68->64->96->128]): 264 / 361 MFMAs per 32-row tile.  The weights (66-92 KB with the
+// shift appended as one more k-row pair) sit in LDS, row-major [k][C], which is conflict-free for the A
+// fragment of the transposed layers (channel on lane&31) and for the B fragment of layer 3 alike; they
+// are read one ds_read_b32 per MFMA (LDS instructions do not take vector-ALU slots).  The gathered input
+// row never touches LDS either: lane (row, kh) loads x[row][2s + kh] directly, 34 dword loads with
+// immediate offsets, issued for the NEXT tile as soon as layer 1 of the current one has consumed them.
+// Per tile ~250 vector-ALU ops (ReLU, swaps, pooling) against 17-23 k cycles of matrix work.
+template <int C2, int NS>
+__global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) {
+  constexpr int K1 = 68, C1 = 64, C3 = 128;
+  constexpr int S1 = K1 / 2, S2 = C1 / 2, S3 = C2 / 2;
+  constexpr int T1 = C1 / 32, T2 = C2 / 32, T3 = C3 / 32;
+  extern __shared__ float lds[];
+  float *W1 = lds;                          // (K1 + 2) x C1 : rows K1, K1+1 = shift, 0
+  float *W2 = W1 + (K1 + 2) * C1;           // (C1 + 2) x C2
+  float *W3 = W2 + (C1 + 2) * C2;           // C2 x C3
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  // staging with 16-byte loads (all leading dimensions and widths are multiples of 4)
+  auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols) {
+    const int c4 = cols / 4;
+    for (int t = tid; t < (k_rows + (shift ? 2 : 0)) * c4; t += blockDim.x) {
+      const int k = t / c4, c = 4 * (t % c4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < k_rows) v = *reinterpret_cast<const float4 *>(w + (size_t)k * ldw + c);
+      else if (k == k_rows) v = *reinterpret_cast<const float4 *>(shift + c);
+      *reinterpret_cast<float4 *>(dst + k * cols + c) = v;
+    }
+  };
+  stage(W1, g.w1, g.ldw1, g.s1, K1, C1);
+  stage(W2, g.w2, g.ldw2, g.s2, C1, C2);
+  stage(W3, g.w3, g.ldw3, nullptr, C2, C3);
+  float sh3[T3];
+#pragma unroll
+  for (int j = 0; j < T3; ++j) sh3[j] = g.s3[32 * j + l31];
+  __syncthreads();
+
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+  const int wave_global = (blockIdx.x * blockDim.x + tid) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = g.rows / 32;
+  int tile = __builtin_amdgcn_readfirstlane(wave_global);
+  if (tile >= ntiles) return;
+
+  float xin[S1];
+  float csub0, csub1;
+  int cnt0, cnt1;
+  auto fetch = [&](int t) {   // t wave-uniform
+    const int c0 = NS == 32 ? t : 2 * t;
+    const int bi = c0 / g.m;
+    const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
+    const int p = g.idx[t * 32 + l31];
+    const float *src = g.a + ((size_t)bi * g.n + p) * K1 + kh;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) xin[s] = src[2 * s];
+    const float *c = g.ctr + (size_t)cj * g.ldctr;
+    csub0 = kh ? c[1] : c[0];         // k = 0 / 1
+    csub1 = kh ? 0.f : c[2];          // k = 2 / 3 (the feature column is not shifted)
+    cnt0 = g.cnt[c0];
+    cnt1 = NS == 32 ? 0 : g.cnt[c0 + 1];
+  };
+  auto to_fragments = [&](const f32x16 &a, float *frag) {   // 16 accumulator registers -> 16 k-step fragments
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = d6_relu(a[4 * G + e]);
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                   : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+      frag[4 * G + 0] = t[0]; frag[4 * G + 1] = t[2]; frag[4 * G + 2] = t[1]; frag[4 * G + 3] = t[3];
+    }
+  };
+
+  float pend[T3][2];
+  int pend_tile = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < T3; ++j) {
+      const int col = 32 * j + l31;
+      if (NS == 32) {
+        g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
+      } else {
+        g.y[(size_t)(2 * pend_tile) * g.ldy + g.col0 + col] = pend[j][0];
+        g.y[(size_t)(2 * pend_tile + 1) * g.ldy + g.col0 + col] = pend[j][1];
+      }
+    }
+  };
+
+  fetch(tile);
+  for (; tile < ntiles; tile += n_waves) {
+    if (pend_tile >= 0) flush();
+    const int my_cnt0 = cnt0, my_cnt1 = cnt1;
+    xin[0] = xin[0] - csub0;
+    xin[1] = xin[1] - csub1;
+    // ---- layer 1 (transposed): K1 -> C1 ----
+    float f1[S2];
+#pragma unroll
+    for (int t = 0; t < T1; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < S1; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[(2 * s + kh) * C1 + 32 * t + l31], xin[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[(K1 + kh) * C1 + 32 * t + l31], one_k0, acc, 0, 0, 0);
+      to_fragments(acc, f1 + 16 * t);
+    }
+    // the input registers are free: start the next tile's gather now, it lands during layers 2 and 3
+    if (tile + n_waves < ntiles) fetch(tile + n_waves);
+    // ---- layer 2 (transposed): C1 -> C2 ----
+    float f2[S3];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(2 * s + kh) * C2 + 32 * t + l31], f1[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(C1 + kh) * C2 + 32 * t + l31], one_k0, acc, 0, 0, 0);
+      to_fragments(acc, f2 + 16 * t);
+    }
+    // ---- layer 3 (rows in the registers): C2 -> C3, pool, shift, ReLU, mask ----
+#pragma unroll
+    for (int j = 0; j < T3; ++j) {
+      f32x16 o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < S3; ++s)
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[s], W3[(2 * s + kh) * C3 + 32 * j + l31], o, 0, 0, 0);
+      float q[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const float mq = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
+        q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
+      }
+      if (NS == 32) {
+        const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
+        pend[j][0] = my_cnt0 > 0 ? mx : 0.f;
+      } else {
+        pend[j][0] = my_cnt0 > 0 ? d6_relu(d6_vmax(q[0], q[1]) + sh3[j]) : 0.f;
+        pend[j][1] = my_cnt1 > 0 ? d6_relu(d6_vmax(q[2], q[3]) + sh3[j]) : 0.f;
+      }
+    }
+    pend_tile = tile;
+  }
+  flush();
+}
+
 }  // namespace
 
 DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
@@ -347,8 +497,14 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   if (rows < 0 || n <= 0 || m <= 0 || (ns != 16 && ns != 32) || !a || !idx || !ctr || !cnt || !w1 || !w2 || !w3 ||
       !s1 || !s2 || !s3 || !y)
     return DET6D_EINVAL;
-  if (lda < 4 || lda > kMaxK1 || (lda & 3) || ((uintptr_t)a & 15) || ldctr < 3) return DET6D_EINVAL;
-  if (c1 <= 0 || c1 > kMaxC || c2 <= 0 || c2 > kMaxC || c3 <= 0 || c3 > kMaxC3) return DET6D_EINVAL;
+  const bool wide = lda == 68 && c1 == 64 && (c2 == 64 || c2 == 96) && c3 == 128 && (ns == 32 || !(m & 1)) && !(ldw1 & 3) &&
+                    !(ldw2 & 3) && !(ldw3 & 3) &&
+                    !(((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)s1 | (uintptr_t)s2) & 15) &&
+                    getenv("DET6D_CHAIN_NO_WIDE") == nullptr;
+  if (!wide) {
+    if (lda < 4 || lda > kMaxK1 || (lda & 3) || ((uintptr_t)a & 15) || ldctr < 3) return DET6D_EINVAL;
+    if (c1 <= 0 || c1 > kMaxC || c2 <= 0 || c2 > kMaxC || c3 <= 0 || c3 > kMaxC3) return DET6D_EINVAL;
+  }
   if (ldw1 < c1 || ldw2 < c2 || ldw3 < c3 || rows % (m * ns) || rows % 32) return DET6D_EINVAL;
   if (rows == 0) return DET6D_OK;
   ChainArgs g;
@@ -359,6 +515,26 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   g.k1 = lda; g.c1 = c1; g.c2 = c2; g.c3 = c3;
   g.y = y; g.ldy = ldy; g.col0 = col0;
   const int ntiles = rows / 32;
+  if (wide) {   // one 512-thread workgroup per CU (weights fill most of its LDS), two waves per SIMD
+    const size_t lds_bytes = sizeof(float) * ((size_t)70 * 64 + (size_t)66 * c2 + (size_t)c2 * 128);
+    const int wb = det6d_divup(ntiles, 8) < 256 ? det6d_divup(ntiles, 8) : 256;
+#define D6_WIDE(C2V, NSV)                                                                                              \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<C2V, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                          (int)lds_bytes);                                                                             \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((mlp_chain_wide_kernel<C2V, NSV>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);     \
+  } while (0)
+    if (c2 == 64 && ns == 16) D6_WIDE(64, 16);
+    else if (c2 == 64) D6_WIDE(64, 32);
+    else if (ns == 16) D6_WIDE(96, 16);
+    else D6_WIDE(96, 32);
+#undef D6_WIDE
+    return det6d_check_launch("det6d_mlp_chain3");
+  }
   int blocks = det6d_divup(ntiles, kChainWaves);
   if (blocks > 256 * 6) blocks = 256 * 6;     // persistent-ish: amortise the weight staging over many tiles
   static const bool use_lds_env = getenv("DET6D_CHAIN_LDS") != nullptr;

@@ -185,10 +185,18 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
     return cnt_a, idx_a, cnt_b, idx_b
 
 
+#: route [68 -> 64 -> 64|96 -> 128] groups through the wide register chain kernel
+CHAIN_WIDE = True
+
+
 def chain_eligible(lda, layers, ns):
     """can a grouped 3-layer MLP run as ONE det6d_mlp_chain3 launch?  layers: [(W, shift, cout, act)] x 3"""
-    return (len(layers) == 3 and lda <= 8 and ns in (16, 32) and layers[0][2] <= 32 and layers[1][2] <= 32
-            and layers[2][2] <= 64 and all(l[3] == 1 for l in layers))
+    if len(layers) != 3 or ns not in (16, 32) or not all(l[3] == 1 for l in layers):
+        return False
+    c1, c2, c3 = layers[0][2], layers[1][2], layers[2][2]
+    if lda == 68 and c1 == 64 and c2 in (64, 96) and c3 == 128:      # wide register chain (SA2-sized groups)
+        return CHAIN_WIDE
+    return lda <= 8 and c1 <= 32 and c2 <= 32 and c3 <= 64
 
 
 def mlp_chain3(rows_pts, idx, ctr, cnt, layers, out, col0):

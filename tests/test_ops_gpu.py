@@ -344,7 +344,8 @@ def test_ball_query_grid_adversarial(ext, oracle_ops):
             np.testing.assert_array_equal(ib.cpu().numpy(), oib)
 
 
-@pytest.mark.parametrize("c_in,widths,ns", [(1, (16, 16, 32), 16), (1, (32, 32, 64), 32), (4, (24, 32, 40), 16), (1, (8, 16, 16), 32)])
+@pytest.mark.parametrize("c_in,widths,ns", [(1, (16, 16, 32), 16), (1, (32, 32, 64), 32), (4, (24, 32, 40), 16), (1, (8, 16, 16), 32),
+                                             (64, (64, 64, 128), 16), (64, (64, 96, 128), 32), (64, (64, 96, 128), 16), (64, (64, 64, 128), 32)])
 def test_mlp_chain3_equals_three_linears(ext, oracle_ops, c_in, widths, ns):
     """the fused narrow-MLP launch against the oracle's three-layer sequence (and hence against three
     det6d_linear calls, which test_linear_* pins to the same oracle)"""
