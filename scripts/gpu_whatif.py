@@ -1,0 +1,46 @@
+"""what-if throughput experiments (NOT results): replace one stage by a trivial stand-in before the graphs are
+captured and see how the step time moves -> that stage's cost in the 24-passes-in-flight regime"""
+import os, sys, time
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from de6d_amd.runtime import load_config, build_model, GraphedDet6D
+from de6d_amd.ops import fused
+from bench import synth_points
+
+def measure(tag, steps=144, depth=24):
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=1234, device='cuda')
+    b, n = 8, 16384
+    points = torch.from_numpy(synth_points(1000, b, n)).cuda()
+    with torch.no_grad():
+        model({'batch_size': b, 'points': points})
+    runners = [GraphedDet6D(model, b, n, points=points) for _ in range(depth)]
+    def run(k):
+        inflight = []
+        for i in range(k):
+            r = runners[i % depth]
+            if len(inflight) >= depth: inflight.pop(0).finalize()
+            inflight.append(r.launch())
+        for r in inflight: r.finalize()
+    run(48); torch.cuda.synchronize(); t0 = time.perf_counter(); run(steps); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-28s %.3f ms/step  %.0f scenes/s" % (tag, dt / steps * 1e3, steps * b / dt), flush=True)
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'base'
+if which == 'nofps':
+    def fake_fps(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
+        idx_out[:, idx_offset:idx_offset + m] = (torch.arange(m, device=xyz.device, dtype=torch.int32) * ((hi - lo) // m) + lo)[None, :]
+    fused.fps_fused = fake_fps
+elif which == 'nolinear':
+    real = fused.linear
+    def fake_linear(*a, **k):
+        return a[4] if len(a) > 4 else k.get('out')
+    # keep shapes: outputs stay whatever the buffers hold
+    import de6d_amd.ops.fused as F
+    _orig = F.L.call
+    def call(name, *args):
+        if name in ('det6d_linear', 'det6d_mlp_chain3'): return 0
+        return _orig(name, *args)
+    F.L.call = call
+measure(which)
