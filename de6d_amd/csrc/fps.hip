@@ -485,6 +485,35 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
                            long long idx_bstride, int idx_add, int init_temp, const float *xyz,
                            const float *temp, int *perm, int *idx, hipStream_t stream);
 
+// ---- profiling stand-ins (DET6D_FPS_STANDIN=1|2, never a result path; scripts/gpu_whatif.py) -------------
+// Same launch shape and duration as the SA1 sampler (one 512-thread workgroup per scene, ~1.35 us per round)
+// but 1: holds 128 VGPRs and sleeps (register / occupancy footprint only), 2: keeps the vector ALU busy
+// from a small register footprint.  Both write a strided index pattern so that the rest of the pass runs.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(512) void fps_standin_kernel(int n, int m, int *idx, int idx_stride, int idx_add) {
+  float r[MODE == 1 ? 120 : 8];
+#pragma unroll
+  for (int i = 0; i < (MODE == 1 ? 120 : 8); ++i) r[i] = threadIdx.x + i;
+  for (int round = 0; round < m; ++round) {
+    if (MODE == 1) {
+      __builtin_amdgcn_s_sleep(40);   // 40 x 64 clocks ~ 1.1 us
+    } else {
+#pragma unroll
+      for (int u = 0; u < 26; ++u)    // ~208 dependent-free VALU ops, like the real scan
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MODE == 1 ? 120 : 8); ++i) { asm volatile("" : "+v"(r[i])); s += r[i]; }
+  int *out = idx + (size_t)blockIdx.x * idx_stride;
+  for (int j = threadIdx.x; j < m; j += blockDim.x) out[j] = (int)(((long long)j * n) / m) + idx_add + (s == -1.f);
+}
+}  // namespace
+
 DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                               const float *scores, float gamma, float *temp, int *idx, int idx_stride,
                               int idx_offset, det6d_stream_t stream) {
@@ -502,6 +531,12 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   const float *x = xyz ? xyz + (size_t)lo * 3 : nullptr;
   int *out = idx ? idx + idx_offset : nullptr;
   if (scores) return launch_fps<true>(b, n, m, x, scores + lo, temp, out, vw, (hipStream_t)stream);
+  static const int standin = getenv("DET6D_FPS_STANDIN") ? atoi(getenv("DET6D_FPS_STANDIN")) : 0;
+  if (standin && n == 16384 && out) {
+    if (standin == 1) hipLaunchKernelGGL(fps_standin_kernel<1>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
+    else hipLaunchKernelGGL(fps_standin_kernel<2>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
+    return det6d_check_launch("det6d_fps_fused(stand-in)");
+  }
   // Opt-in (DET6D_FPS_CELLS_MIN_N=4096|8192|16384): the exact spatially pruned cell sampler of
   // fps_cells.hip (its Morton permutation lives in `temp`, which is free because the min-distances start
   // at 1e10 implicitly).  Bit-exact, but measured on MI355X at 1.39 us/round for 16384 points against

@@ -418,6 +418,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     return det6d_check_launch("det6d_linear");
   }
   static const int force_k_max = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : 0;
+  static const int force_n_max = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : 512;
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
     // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles.  These
@@ -426,7 +427,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     if (gm * det6d_divup(a->ncols, 128) < 256)
       hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                          dim3(256), 0, s, *a);
-    else if (a->ncols <= 512 && a->k <= force_k_max)
+    else if (a->ncols <= force_n_max && a->k <= force_k_max)
       // 128x64 tiles (5 waves/SIMD) used to win 2-7 % on short K loops; with the vector-ALU-free main loop
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
       // off by default (DET6D_LINEAR_K64MAX = largest K that still takes it)
