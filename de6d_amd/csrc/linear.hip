@@ -40,7 +40,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // On gfx950 the fp32 MFMA shares the VALU: every vector ALU instruction in the loop is ~5 cycles taken from
 // the matrix pipe (scripts/hiptests/mfma_valu_overlap.hip), and the predicated form had ~56 of them per slab.
 template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1, int FASTLVL = 2>
-__global__ __launch_bounds__(256) void linear_kernel(const det6d_linear_args g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void linear_kernel(const det6d_linear_args g) {
   constexpr bool FAST = FASTLVL >= 2;      // predicate-free buffer_load main loop
   constexpr bool FAST_EPI = FASTLVL >= 1;  // predicate-free buffer_store epilogue on interior tiles (32-bit offsets)
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
@@ -418,6 +418,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     return det6d_check_launch("det6d_linear");
   }
   static const int force_k_max = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : 0;
+  static const int bk32 = getenv("DET6D_LINEAR_BK32") ? atoi(getenv("DET6D_LINEAR_BK32")) : 0;   // K from which BK = 32 is used
   static const int force_n_max = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : 512;
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
@@ -432,6 +433,8 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
       // off by default (DET6D_LINEAR_K64MAX = largest K that still takes it)
       hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+    else if (bk32 && a->k >= bk32)
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
