@@ -322,10 +322,13 @@ typedef struct det6d_linear_args {
 } det6d_linear_args;
 int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
 
-/* The three pointwise layers of a NARROW grouped MLP (row width lda <= 8, hidden widths c1, c2 <= 32,
- * output width c3 <= 64, nsample 16 or 32) in one launch: identical, bit for bit, to
+/* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to
  *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)
- * but the (rows x c1), (rows x c2) intermediates stay in LDS (csrc/mlp_chain.hip).
+ * but the (rows x c1), (rows x c2) intermediates never leave the CU (csrc/mlp_chain.hip).  Supported shapes:
+ *   narrow: row width lda <= 8, c1, c2 <= 32, c3 <= 64 (register kernel for lda = 4 with (16,16,32) / (32,32,64),
+ *           LDS kernel otherwise);
+ *   wide:   lda = 68, c1 = 64, c2 = 64 or 96, c3 = 128, 16-byte aligned weights / shifts, m even when ns = 16.
+ * Anything else returns DET6D_EINVAL (callers fall back to three det6d_linear calls).
  * y[(r / ns) * ldy + col0 + c], r over b*m*ns rows. */
 int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
                      const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1, const float *s1,
