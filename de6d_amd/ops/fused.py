@@ -2,6 +2,7 @@
 (include/det6d_ops.h, section "fused engine ops").  Outputs are caller- or wrapper-allocated
 device tensors; every call is asynchronous on the current stream."""
 import ctypes
+import os
 
 import torch
 
@@ -186,7 +187,7 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
 
 
 #: route [68 -> 64 -> 64|96 -> 128] groups through the wide register chain kernel
-CHAIN_WIDE = True
+CHAIN_WIDE = os.environ.get('DET6D_CHAIN_NO_WIDE') is None   # the C entry honours the same switch
 
 
 def chain_eligible(lda, layers, ns):

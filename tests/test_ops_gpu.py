@@ -1,6 +1,8 @@
 """GPU parity tests: every C-ABI op of libdet6d_hip.so (through the reference-shaped module
 functions) against the CPU oracle on the same seeded inputs.  Bit-exact for indices, masks and
 for everything computed with the shared deterministic arithmetic."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -377,3 +379,17 @@ def test_mlp_chain3_equals_three_linears(ext, oracle_ops, c_in, widths, ns):
     ref = np.zeros((b * m, widths[2] + 3), np.float32)
     oracle_ops.linear(h, layers_np[2][0][:, :widths[2]], layers_np[2][1], 1, cnt=cnt, pool=ns, out=ref, col0=3)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_fallback_kernels_via_env_switches(tmp_path):
+    """the plain predicated GEMM loader (tensors beyond 32-bit offsets), the LDS chain kernel and the
+    three-GEMM route for SA2-sized groups are selected by size / shape at run time; force them with their
+    environment switches in a child process and rerun the parity tests that cover them"""
+    import subprocess
+    import sys
+    env = dict(os.environ, DET6D_LINEAR_NO_FAST='1', DET6D_CHAIN_LDS='1', DET6D_CHAIN_NO_WIDE='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_ops_gpu.py'), '-q', '-x', '-m', 'gpu',
+                          '-k', 'test_linear or (chain3 and not widths4 and not widths5 and not widths6 and not widths7)'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'passed' in out.stdout
