@@ -211,6 +211,28 @@ def test_linear_grouped_pool_bit_exact(ext, oracle_ops, n, m, ns, c, n1):
     np.testing.assert_array_equal(outp.cpu().numpy(), refp)
 
 
+def test_linear_random_shapes_bit_exact(ext, oracle_ops):
+    """seeded sweep over shapes that land on every tile variant, interior and edge tiles, full / short / odd
+    K slabs (the buffer-load fast path, its predicated first / last slab, both epilogues)"""
+    fused = ext[2]
+    rng = np.random.default_rng(2025)
+    shapes = [(32768, 132, 128), (33000, 260, 256), (40000, 96, 128), (36864, 64, 96), (32896, 17, 40), (2048, 512, 128),
+              (65600, 31, 300), (16384, 16, 1), (70000, 48, 33)]
+    shapes += [(int(rng.integers(1, 40000)), int(rng.integers(1, 300)), int(rng.integers(1, 300))) for _ in range(10)]
+    for rows, k, n in shapes:
+        lda, ldw = (k + 3) // 4 * 4 + 4 * int(rng.integers(0, 2)), (n + 3) // 4 * 4
+        a = rng.normal(size=(rows, lda)).astype(np.float32)
+        a[:, k:] = np.nan                       # columns beyond K must never be read into the result
+        w = (rng.normal(size=(k, ldw)) / np.sqrt(k)).astype(np.float32)
+        shift = rng.normal(size=(n,)).astype(np.float32)
+        act = int(rng.integers(0, 2))
+        out = torch.full((rows, n + 3), 7.0, device="cuda")
+        fused.linear(dev(a), dev(w), dev(shift), act, out, k=k, ncols=n, col0=1)
+        ref = np.full((rows, n + 3), 7.0, np.float32)
+        oracle_ops.linear(np.nan_to_num(a), w[:, :n], shift, act, k=k, out=ref, col0=1)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=str((rows, k, n, lda, act)))
+
+
 def test_head_elementwise_bit_exact(ext, oracle_ops):
     fused = ext[2]
     rng = np.random.default_rng(9)
