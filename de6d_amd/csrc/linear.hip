@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
     csub[i][0] = csub[i][1] = csub[i][2] = 0.f;
     if (r < R) {
       if (g.mode == DET6D_A_GROUPED) {
-        const int cj = r / g.ns;
-        const int bi = cj / g.m;
+        // ns and m are powers of two in every Det6D layer: shifts instead of two ~20-instruction integer
+        // divisions per row (uniform branches; vector-ALU work is matrix time here)
+        int cj, bi;
+        if ((g.ns & (g.ns - 1)) == 0) cj = r >> __builtin_ctz(g.ns); else cj = r / g.ns;
+        if ((g.m & (g.m - 1)) == 0) bi = cj >> __builtin_ctz(g.m); else bi = cj / g.m;
         const int p = g.idx[r];
         arow[i] = g.a + ((size_t)bi * g.n + p) * g.lda;
         if (akq == 0) {
