@@ -1,6 +1,7 @@
 // micro-benchmark: the GEMM inner loop (operands from LDS, 2x2 MFMA tiles per wave, BK = 16) with
 //  V0: k-major tiles read by ds_read_b32 pairs (what linear.hip does)
 //  V1: per-lane-half k-contiguous tiles [kh][row][8] (XOR-swizzled 16-B slots) read by ds_read_b128
+//  V2: A as V1, B as V0
 // No global loads, no barriers inside the loop: isolates LDS operand delivery + MFMA issue.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -31,6 +32,30 @@ __global__ __launch_bounds__(256) void k(float *out, int slabs) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else if (VARIANT == 2) {       // A by ds_read_b128 (k-contiguous per lane half), B k-major by ds_read_b32
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 a4[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + l31 + 32 * i;
+          a4[i] = *reinterpret_cast<const float4 *>(&As[((kh * BM + row) * 2 + (h ^ ((row >> 3) & 1))) * 4]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ks = 4 * h + t;
+          float bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = Bs[(2 * ks + kh) * BN + wn * 64 + l31 + 32 * j];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float a = t == 0 ? a4[i].x : t == 1 ? a4[i].y : t == 2 ? a4[i].z : a4[i].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
       }
     } else {
 #pragma unroll
@@ -65,9 +90,9 @@ __global__ __launch_bounds__(256) void k(float *out, int slabs) {
 }
 
 template <int VARIANT>
-void run(int blocks_per_cu) {
+void run(int blocks_per_cu, int slabs = 400) {
   float *d;
-  const int blocks = 256 * blocks_per_cu, slabs = 400;
+  const int blocks = 256 * blocks_per_cu;
   hipMalloc(&d, sizeof(float) * blocks * 256);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,12 +104,16 @@ void run(int blocks_per_cu) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double flops = (double)blocks * 4 * slabs * 32 * 4096.0;
-  printf("variant %d, %d blocks/CU (= waves/SIMD): %.1f TF\n", VARIANT, blocks_per_cu, flops / ms / 1e9);
+  printf("variant %d, %d blocks/CU (= waves/SIMD), %4d slabs, %.2f ms: %.1f TF\n", VARIANT, blocks_per_cu, slabs, ms, flops / ms / 1e9);
   hipFree(d);
 }
 
 int main() {
   for (int b = 1; b <= 3; ++b) run<0>(b);
   for (int b = 1; b <= 3; ++b) run<1>(b);
+  for (int b = 3; b <= 4; ++b) run<2>(b);
+  run<0>(4); run<1>(4);
+  // duration sweep at 3 waves/SIMD: separates occupancy from clock management under sustained matrix load
+  run<0>(3, 100); run<0>(3, 400); run<0>(3, 800); run<0>(3, 1600); run<0>(3, 6400); run<0>(4, 100); run<0>(4, 300); run<0>(2, 600);
   return 0;
 }
