@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   // A short last slab (K = 68, 132, 260: [xyz | C | pad] rows) is peeled out of the main loop and issues
   // only the k-steps that hold data; the skipped steps would multiply zeros, so every output's chain
   // is unchanged.  (A branch INSIDE the main loop costs 10-20 %: it breaks the load/MFMA overlap.)
-  auto compute_tail = [&](int kleft) {
+  auto compute_tail = [&](int buf, int kleft) {
     const int nks = (kleft + 1) >> 1;
 #pragma unroll 1
-    for (int ks = 0; ks < nks; ++ks) kstep(As_all, Bs_all, ks);
+    for (int ks = 0; ks < nks; ++ks) kstep(As_all + buf * BK * LDA_S, Bs_all + buf * BK * BN, ks);
   };
 
   if (FAST && BK <= K) {
@@ -273,20 +273,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
     if (k0 < K) {
       store_tile(0);
       __syncthreads();
-      compute_tail(K - k0);
+      compute_tail(0, K - k0);
     }
   } else {
+    // two LDS buffers: ONE barrier per slab (the slab after next is written while nobody reads it)
     store_tile(0);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    int buf = 0, k0 = 0;
+    if (FAST) {
+      for (; k0 + 2 * BK <= K; k0 += BK) {
+        load_tile_fast(k0 + BK);
+        compute(buf);
+        store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    for (; k0 + BK <= K; k0 += BK) {
       const bool more = k0 + BK < K;
       if (more) load_tile(k0 + BK);
       compute(buf);
-      if (more) store_tile(buf ^ 1);   // nobody reads buf^1 during this iteration
+      if (more) store_tile(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
+    if (k0 < K) compute_tail(buf, K - k0);
   }
 
   // ---- epilogue ----
@@ -421,6 +432,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     return det6d_check_launch("det6d_linear");
   }
   static const int force_k_max = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : 0;
+  static const bool nbuf2 = getenv("DET6D_LINEAR_NBUF2") != nullptr;   // double-buffered LDS tiles, one barrier per slab
   static const int bk32 = getenv("DET6D_LINEAR_BK32") ? atoi(getenv("DET6D_LINEAR_BK32")) : 0;   // K from which BK = 32 is used
   static const int force_n_max = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : 512;
   if (a->ncols > 64) {
@@ -436,6 +448,8 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
       // off by default (DET6D_LINEAR_K64MAX = largest K that still takes it)
       hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+    else if (nbuf2)
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else if (bk32 && a->k >= bk32)
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else
