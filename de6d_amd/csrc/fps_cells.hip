@@ -240,6 +240,154 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-skip sampler: the fat-thread kernel of fps.hip on Morton-sorted points, with ONE bounding box per
+// wave.  A wave whose box is at least sqrt(its current maximum) away from the new sample cannot change
+// and keeps its cached arg-max; only the waves near the sample rescan their 32 points per lane.  Same
+// register footprint and round latency as the fat kernel, but ~1/5 of its vector-ALU instructions once
+// the first few hundred samples are placed — and on gfx950 every VALU instruction of a co-resident kernel
+// is time taken from the fp32 MFMAs of the GEMM waves on that SIMD.
+// Exactness: (1) the box test is a floating-point lower bound of the distance the scan would compute
+// (monotone ops, see the top of this file); (2) ties: the pre-pass orders the 32 points of a lane by the
+// reference's tie key, so the strict `>` of the scan keeps the right one inside a lane; ties between
+// lanes / waves take the explicit min-key slow path.
+// ------------------------------------------------------------------------------------------------
+template <int GS>
+__global__ __launch_bounds__(512) void skip_group_order_kernel(int n, int log2s, int *__restrict__ perm) {
+  // one thread per group of GS consecutive sorted positions (= one lane's slots): insertion sort by tie key
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  int *p = perm + (size_t)blockIdx.y * n + (size_t)g * GS;
+  if (g * GS >= n) return;
+  int v[GS];
+  unsigned key[GS];
+  for (int i = 0; i < GS; ++i) { v[i] = p[i]; key[i] = tie_key(v[i], log2s); }
+  for (int i = 1; i < GS; ++i) {
+    const int vi = v[i];
+    const unsigned ki = key[i];
+    int j = i;
+    while (j > 0 && key[j - 1] > ki) { v[j] = v[j - 1]; key[j] = key[j - 1]; --j; }
+    v[j] = vi; key[j] = ki;
+  }
+  for (int i = 0; i < GS; ++i) p[i] = v[i];
+}
+
+template <int LO, int HI, int N>
+__device__ __forceinline__ void skip_pick(int ws, int wl, const float (&px)[N], const float (&py)[N],
+                                          const float (&pz)[N], float &sx, float &sy, float &sz) {
+  if constexpr (HI - LO == 1) {
+    sx = d6_readlane_f(px[LO], wl);
+    sy = d6_readlane_f(py[LO], wl);
+    sz = d6_readlane_f(pz[LO], wl);
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (ws < MID) skip_pick<LO, MID>(ws, wl, px, py, pz, sx, sy, sz);
+    else skip_pick<MID, HI>(ws, wl, px, py, pz, sx, sy, sz);
+  }
+}
+
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+
+template <int NW, int SLOTS>
+__global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log2s, long long xyz_bstride,
+                                                           long long idx_bstride, int idx_add,
+                                                           const float *__restrict__ xyz,
+                                                           const int *__restrict__ perm, int *__restrict__ idxs) {
+  constexpr int H = SLOTS / 2;
+  __shared__ CellSlot slots[2][NW];
+  __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
+  const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
+  xyz += (size_t)blockIdx.x * xyz_bstride;
+  perm += (size_t)blockIdx.x * n;
+  idxs += (size_t)blockIdx.x * idx_bstride;
+
+  float px[SLOTS], py[SLOTS], pz[SLOTS], pt[SLOTS];
+  float lox = 3.0e38f, loy = 3.0e38f, loz = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f, hiz = -3.0e38f;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int k = perm[h * SLOTS + s];
+    korig[h * SLOTS + s] = (unsigned short)k;
+    px[s] = xyz[(size_t)k * 3 + 0];
+    py[s] = xyz[(size_t)k * 3 + 1];
+    pz[s] = xyz[(size_t)k * 3 + 2];
+    asm volatile("" : "+v"(px[s]), "+v"(py[s]), "+v"(pz[s]));
+    pt[s] = 1e10f;
+    lox = d6_vmin(lox, px[s]); hix = d6_vmax(hix, px[s]);
+    loy = d6_vmin(loy, py[s]); hiy = d6_vmax(hiy, py[s]);
+    loz = d6_vmin(loz, pz[s]); hiz = d6_vmax(hiz, pz[s]);
+  }
+  // the wave's bounding box (uniform)
+  lox = d6_wave_min(lox); hix = d6_wave_max(hix);
+  loy = d6_wave_min(loy); hiy = d6_wave_max(hiy);
+  loz = d6_wave_min(loz); hiz = d6_wave_max(hiz);
+  __syncthreads();
+
+  float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+  if (h == 0) idxs[0] = idx_add;
+  // cached arg-max of this wave (uniform)
+  float cw_val = __builtin_inff(), cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+  int cw_k = 0;
+
+  for (int r = 1; r < m; ++r) {
+    // 1. can any point of this wave change?  (lb <= every distance the scan would compute; cw_val >= every pt)
+    const float gx = fmaxf(0.f, fmaxf(lox - cx, cx - hix));
+    const float gy = fmaxf(0.f, fmaxf(loy - cy, cy - hiy));
+    const float gz = fmaxf(0.f, fmaxf(loz - cz, cz - hiz));
+    const float lb = d6_sqdist(gx, gy, gz);
+    if (!(lb >= cw_val)) {   // wave-uniform branch
+      float best = -1.0f;
+      int bs = 0;
+      const f32x2s c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+      for (int q = 0; q < H; ++q) {
+        const f32x2s dx = f32x2s{px[2 * q], px[2 * q + 1]} - c2x;
+        const f32x2s dy = f32x2s{py[2 * q], py[2 * q + 1]} - c2y;
+        const f32x2s dz = f32x2s{pz[2 * q], pz[2 * q + 1]} - c2z;
+        f32x2s d = dy * dy;
+        d = __builtin_elementwise_fma(dx, dx, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int s = 2 * q + e;
+          const float t = d6_vmin(d[e], pt[s]);
+          pt[s] = t;
+          const bool up = t > best;
+          bs = up ? s : bs;
+          best = up ? t : best;
+        }
+      }
+      const float wmax = d6_wave_max(best);
+      const unsigned long long tie = __ballot(best == wmax);
+      int wl = __builtin_ctzll(tie);
+      if (__popcll(tie) != 1) wl = min_key_lane(tie, (int)korig[h * SLOTS + bs], log2s);
+      const int ws = d6_readlane_i(bs, wl);
+      cw_val = wmax;
+      cw_k = (int)korig[(wave * 64 + wl) * SLOTS + ws];
+      skip_pick<0, SLOTS>(ws, wl, px, py, pz, cw_x, cw_y, cw_z);
+    }
+    // 2. block arg-max over the waves' cached maxima
+    CellSlot *sl = slots[r & 1];
+    if (lane == 0) {
+      sl[wave].val = cw_val;
+      sl[wave].idx = cw_k;
+      sl[wave].x = cw_x; sl[wave].y = cw_y; sl[wave].z = cw_z;
+    }
+    __syncthreads();
+    const int src = lane & (NW - 1);
+    const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
+    const int i2 = sl[src].idx;
+    const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
+    const float bmax = d6_wave_max(v2);
+    const unsigned long long tie2 = __ballot(v2 == bmax);
+    int ww = __builtin_ctzll(tie2);
+    if (__popcll(tie2) != 1) ww = min_key_lane(tie2, i2, log2s);
+    const int old = d6_readlane_i(i2, ww);
+    cx = d6_readlane_f(x2, ww);
+    cy = d6_readlane_f(y2, ww);
+    cz = d6_readlane_f(z2, ww);
+    if (h == 0) idxs[r] = old + idx_add;
+  }
+}
+
 }  // namespace
 
 // Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
@@ -248,6 +396,22 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
                            const float *temp, int *perm, int *idx, hipStream_t stream) {
   dim3 grid(b);
   static const int dbg = getenv("DET6D_FPS_DBG") ? atoi(getenv("DET6D_FPS_DBG")) : 0;  // timing experiments only
+  // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
+  // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
+  static const int skip = getenv("DET6D_FPS_SKIP") ? atoi(getenv("DET6D_FPS_SKIP")) : 16;
+  if (skip && n == 16384 && init_temp) {
+    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    if (skip != 8) {
+      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<16, 16>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, xyz, perm, idx);
+    } else {
+      hipLaunchKernelGGL(skip_group_order_kernel<32>, dim3(1, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<8, 32>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, xyz, perm, idx);
+    }
+    return det6d_check_launch("det6d_fps (wave skip)");
+  }
   if (n == 16384) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
     hipLaunchKernelGGL((fps_cells_kernel<8, 32>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride,

@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for v in 0 1; do
-  echo "== NBUF2=$v"
-  if [ $v = 1 ]; then export DET6D_LINEAR_NBUF2=1; fi
-  python scripts/gpu_linear_breakdown.py 2>&1 | tail -20 | cut -c1-62 | grep "K  512 N 1024\|K  256 N\|K  260 N  256\|K  128 N  256\|K  132 N  128\|total"
-done
-unset DET6D_LINEAR_NBUF2
-DET6D_LINEAR_NBUF2=1 python -m pytest tests/test_ops_gpu.py -x -q -k "test_linear" 2>&1 | tail -1
+run() { python bench.py --cpu-scenes 0 --no-roofline 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys; d=json.load(open('/tmp/o.json')); print(sys.argv[1], d['value'], d['ms_per_step'])" "$1"; }
+DET6D_FPS_SKIP=16 python scripts/gpu_fps_cells.py 2>&1 | head -3
+DET6D_FPS_SKIP=16 run skip16
+run skip8
+DET6D_FPS_SKIP=0 run fat

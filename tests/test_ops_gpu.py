@@ -327,14 +327,15 @@ def test_fused_sampler_and_helpers(ext, oracle_ops):
     np.testing.assert_array_equal(xyz2.cpu().numpy(), oxyz2)
 
 
-def test_pruned_cell_fps_is_exact():
-    """fps_cells.hip (opt-in through DET6D_FPS_CELLS_MIN_N): Morton cells + bounding-box skip test must
-    give the oracle's picks bit for bit, duplicates and all-equal clouds included"""
-    import os
+@pytest.mark.parametrize("skip", ["16", "8", "0"])
+def test_pruned_fps_kernels_are_exact(skip):
+    """fps_cells.hip: the wave-skip sampler (default for 16384 points: 16 waves x 16 slots; 8 x 32 variant) and
+    the cell sampler (DET6D_FPS_SKIP=0 + DET6D_FPS_CELLS_MIN_N) must give the oracle's picks bit for bit,
+    duplicates and all-equal clouds included"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DET6D_FPS_CELLS_MIN_N="4096")
+    env = dict(os.environ, DET6D_FPS_CELLS_MIN_N="4096", DET6D_FPS_SKIP=skip)
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fps_cells.py")], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
