@@ -432,6 +432,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     return det6d_check_launch("det6d_linear");
   }
   static const int force_k_max = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : 0;
+  static const bool fast64 = getenv("DET6D_LINEAR_FAST64") ? atoi(getenv("DET6D_LINEAR_FAST64")) != 0 : false;
   static const bool nbuf2 = getenv("DET6D_LINEAR_NBUF2") != nullptr;   // double-buffered LDS tiles, one barrier per slab
   static const int bk32 = getenv("DET6D_LINEAR_BK32") ? atoi(getenv("DET6D_LINEAR_BK32")) : 0;   // K from which BK = 32 is used
   static const int force_n_max = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : 512;
@@ -440,9 +441,14 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles.  These
     // launches are latency-bound (one wave per SIMD): the buffer-load fast path measured 5-9 % SLOWER
     // there, so they keep the plain loader (FAST = false).
-    if (gm * det6d_divup(a->ncols, 128) < 256)
-      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
-                         dim3(256), 0, s, *a);
+    if (gm * det6d_divup(a->ncols, 128) < 256) {
+      if (fast64)
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 2>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+                           dim3(256), 0, s, *a);
+      else
+        hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
+                           dim3(256), 0, s, *a);
+    }
     else if (a->ncols <= force_n_max && a->k <= force_k_max)
       // 128x64 tiles (5 waves/SIMD) used to win 2-7 % on short K loops; with the vector-ALU-free main loop
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
@@ -455,7 +461,9 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     else
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
-    if (gm < 128)
+    if (gm < 128 && fast64)
+      hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 2>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
+    else if (gm < 128)
       hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm), dim3(256), 0, s, *a);

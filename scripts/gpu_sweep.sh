@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python scripts/gpu_whatif.py base 2>&1 | tail -1
-python scripts/gpu_whatif.py nofps 2>&1 | tail -1
-python bench.py --batch 8 --streams 1 --cpu-scenes 0 --no-roofline --steps 60 --warmup 10 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json; d=json.load(open('/tmp/o.json')); print('batch 8, 1 stream:', d['value'], d['ms_per_step'])"
-python bench.py --batch 1 --streams 1 --cpu-scenes 0 --no-roofline --steps 100 --warmup 20 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json; d=json.load(open('/tmp/o.json')); print('batch 1, 1 stream:', d['value'], d['ms_per_step'])"
+run() { python bench.py --cpu-scenes 0 --no-roofline 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys; d=json.load(open('/tmp/o.json')); print(sys.argv[1], d['value'], d['ms_per_step'])" "$1"; }
+DET6D_LINEAR_FAST64=1 run fast64
+run base
+DET6D_LINEAR_FAST64=1 run fast64_again

@@ -43,4 +43,11 @@ elif which == 'nolinear':
         if name in ('det6d_linear', 'det6d_mlp_chain3'): return 0
         return _orig(name, *args)
     F.L.call = call
+if which == 'nosmall':
+    import de6d_amd.ops.fused as F
+    _orig = F.L.call
+    def call(name, *args):
+        if name == 'det6d_linear' and args[0]._obj.rows <= 8192: return 0
+        return _orig(name, *args)
+    F.L.call = call
 measure(which)
