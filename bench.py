@@ -198,7 +198,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=14, help='passes in flight (14 on 16 hardware queues measured best: 8 -> 3395, 12 -> 3900, 14 -> 4005, 16 -> 3670, 24 -> 3800 scenes/s)')
+    ap.add_argument('--streams', type=int, default=15, help='passes in flight (15 on 16 hardware queues measured best: 8 -> 3395, 12 -> 3900, 14 -> 4005, 15 -> 4050, 16 -> 3670, 24 -> 3800 scenes/s)')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
