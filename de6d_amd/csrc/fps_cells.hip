@@ -91,20 +91,21 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bs
     xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
     ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
   }
-  const float sx = xmax > xmin ? 65535.0f / (xmax - xmin) : 0.f;
-  const float sy = ymax > ymin ? 65535.0f / (ymax - ymin) : 0.f;
+  // 10 bits per axis (7 cm cells on a KITTI scene): 20-bit keys = 5 radix passes instead of 8
+  const float sx = xmax > xmin ? 1023.0f / (xmax - xmin) : 0.f;
+  const float sy = ymax > ymin ? 1023.0f / (ymax - ymin) : 0.f;
   unsigned key[IPT];
   int val[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     float fx = (x[i] - xmin) * sx, fy = (y[i] - ymin) * sy;
-    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 65535.f) : 0.f;
-    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 65535.f) : 0.f;
+    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1023.f) : 0.f;
+    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 1023.f) : 0.f;
     key[i] = (part1by1((unsigned)fx) << 1) | part1by1((unsigned)fy);
     val[i] = tid * IPT + i;
   }
   __syncthreads();
-  Sort(sort_tmp).Sort(key, val);
+  Sort(sort_tmp).Sort(key, val, 0, 20);
 #pragma unroll
   for (int i = 0; i < IPT; ++i) perm[tid * IPT + i] = val[i];
 }
