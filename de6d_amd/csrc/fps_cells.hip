@@ -288,12 +288,15 @@ __device__ __forceinline__ void skip_pick(int ws, int wl, const float (&px)[N], 
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 
-template <int NW, int SLOTS>
+// G groups per wave: group g of a wave = slots g*SG .. (g+1)*SG-1 of its 64 lanes = 64*SG consecutive sorted
+// points with their own bounding box and cached arg-max (G = 1: one box per wave).
+template <int NW, int SLOTS, int G>
 __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log2s, long long xyz_bstride,
-                                                           long long idx_bstride, int idx_add,
+                                                           long long idx_bstride, int idx_add, int dbg,
                                                            const float *__restrict__ xyz,
                                                            const int *__restrict__ perm, int *__restrict__ idxs) {
-  constexpr int H = SLOTS / 2;
+  constexpr int SG = SLOTS / G, HG = SG / 2;
+  static_assert(SG * G == SLOTS && SG % 2 == 0, "group layout");
   __shared__ CellSlot slots[2][NW];
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
@@ -302,70 +305,95 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   idxs += (size_t)blockIdx.x * idx_bstride;
 
   float px[SLOTS], py[SLOTS], pz[SLOTS], pt[SLOTS];
-  float lox = 3.0e38f, loy = 3.0e38f, loz = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f, hiz = -3.0e38f;
+  float lox[G], loy[G], loz[G], hix[G], hiy[G], hiz[G];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int k = perm[h * SLOTS + s];
-    korig[h * SLOTS + s] = (unsigned short)k;
-    px[s] = xyz[(size_t)k * 3 + 0];
-    py[s] = xyz[(size_t)k * 3 + 1];
-    pz[s] = xyz[(size_t)k * 3 + 2];
-    asm volatile("" : "+v"(px[s]), "+v"(py[s]), "+v"(pz[s]));
-    pt[s] = 1e10f;
-    lox = d6_vmin(lox, px[s]); hix = d6_vmax(hix, px[s]);
-    loy = d6_vmin(loy, py[s]); hiy = d6_vmax(hiy, py[s]);
-    loz = d6_vmin(loz, pz[s]); hiz = d6_vmax(hiz, pz[s]);
+  for (int g = 0; g < G; ++g) {
+    float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+      const int s = g * SG + j;
+      const int pos = ((wave * G + g) * 64 + lane) * SG + j;
+      const int k = perm[pos];
+      korig[pos] = (unsigned short)k;
+      px[s] = xyz[(size_t)k * 3 + 0];
+      py[s] = xyz[(size_t)k * 3 + 1];
+      pz[s] = xyz[(size_t)k * 3 + 2];
+      asm volatile("" : "+v"(px[s]), "+v"(py[s]), "+v"(pz[s]));
+      pt[s] = 1e10f;
+      ax = d6_vmin(ax, px[s]); bx = d6_vmax(bx, px[s]);
+      ay = d6_vmin(ay, py[s]); by = d6_vmax(by, py[s]);
+      az = d6_vmin(az, pz[s]); bz = d6_vmax(bz, pz[s]);
+    }
+    lox[g] = d6_wave_min(ax); hix[g] = d6_wave_max(bx);   // the group's bounding box (uniform)
+    loy[g] = d6_wave_min(ay); hiy[g] = d6_wave_max(by);
+    loz[g] = d6_wave_min(az); hiz[g] = d6_wave_max(bz);
   }
-  // the wave's bounding box (uniform)
-  lox = d6_wave_min(lox); hix = d6_wave_max(hix);
-  loy = d6_wave_min(loy); hiy = d6_wave_max(hiy);
-  loz = d6_wave_min(loz); hiz = d6_wave_max(hiz);
   __syncthreads();
 
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
   if (h == 0) idxs[0] = idx_add;
-  // cached arg-max of this wave (uniform)
-  float cw_val = __builtin_inff(), cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
-  int cw_k = 0;
+  // cached arg-max of every group of this wave (uniform)
+  float cg_val[G], cg_x[G], cg_y[G], cg_z[G];
+  int cg_k[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { cg_val[g] = __builtin_inff(); cg_x[g] = cg_y[g] = cg_z[g] = 0.f; cg_k[g] = 0; }
 
   for (int r = 1; r < m; ++r) {
-    // 1. can any point of this wave change?  (lb <= every distance the scan would compute; cw_val >= every pt)
-    const float gx = fmaxf(0.f, fmaxf(lox - cx, cx - hix));
-    const float gy = fmaxf(0.f, fmaxf(loy - cy, cy - hiy));
-    const float gz = fmaxf(0.f, fmaxf(loz - cz, cz - hiz));
-    const float lb = d6_sqdist(gx, gy, gz);
-    if (!(lb >= cw_val)) {   // wave-uniform branch
-      float best = -1.0f;
-      int bs = 0;
-      const f32x2s c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-      for (int q = 0; q < H; ++q) {
-        const f32x2s dx = f32x2s{px[2 * q], px[2 * q + 1]} - c2x;
-        const f32x2s dy = f32x2s{py[2 * q], py[2 * q + 1]} - c2y;
-        const f32x2s dz = f32x2s{pz[2 * q], pz[2 * q + 1]} - c2z;
-        f32x2s d = dy * dy;
-        d = __builtin_elementwise_fma(dx, dx, d);
-        d = __builtin_elementwise_fma(dz, dz, d);
+    for (int g = 0; g < G; ++g) {
+      // 1. can any point of this group change?  (lb <= every distance the scan would compute; cg_val >= every pt)
+      const float gx = fmaxf(0.f, fmaxf(lox[g] - cx, cx - hix[g]));
+      const float gy = fmaxf(0.f, fmaxf(loy[g] - cy, cy - hiy[g]));
+      const float gz = fmaxf(0.f, fmaxf(loz[g] - cz, cz - hiz[g]));
+      const float lb = d6_sqdist(gx, gy, gz);
+      if (!(lb >= cg_val[g]) && !(dbg == 3 && r > 1)) {   // wave-uniform branch (dbg 3: fixed per-round cost only)
+        float best = -1.0f;
+        int bs = 0;
+        const f32x2s c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int s = 2 * q + e;
-          const float t = d6_vmin(d[e], pt[s]);
-          pt[s] = t;
-          const bool up = t > best;
-          bs = up ? s : bs;
-          best = up ? t : best;
+        for (int q = 0; q < HG; ++q) {
+          const int s0 = g * SG + 2 * q;
+          const f32x2s dx = f32x2s{px[s0], px[s0 + 1]} - c2x;
+          const f32x2s dy = f32x2s{py[s0], py[s0 + 1]} - c2y;
+          const f32x2s dz = f32x2s{pz[s0], pz[s0 + 1]} - c2z;
+          f32x2s d = dy * dy;
+          d = __builtin_elementwise_fma(dx, dx, d);
+          d = __builtin_elementwise_fma(dz, dz, d);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int s = s0 + e;
+            const float t = d6_vmin(d[e], pt[s]);
+            pt[s] = t;
+            const bool up = t > best;
+            bs = up ? 2 * q + e : bs;      // slot within the group
+            best = up ? t : best;
+          }
         }
+        const float wmax = d6_wave_max(best);
+        const unsigned long long tie = __ballot(best == wmax);
+        int wl = __builtin_ctzll(tie);
+        const int gbase = (wave * G + g) * 64;
+        if (__popcll(tie) != 1) wl = min_key_lane(tie, (int)korig[(gbase + lane) * SG + bs], log2s);
+        const int ws = d6_readlane_i(bs, wl);
+        cg_val[g] = wmax;
+        cg_k[g] = (int)korig[(gbase + wl) * SG + ws];
+        float sx, sy, sz;
+        if (g == 0) skip_pick<0, SG>(ws, wl, px, py, pz, sx, sy, sz);
+        if (G > 1 && g == 1) skip_pick<(G > 1 ? SG : 0), (G > 1 ? 2 * SG : SG)>(ws + SG, wl, px, py, pz, sx, sy, sz);
+        if (G > 2 && g == 2) skip_pick<(G > 2 ? 2 * SG : 0), (G > 2 ? 3 * SG : SG)>(ws + 2 * SG, wl, px, py, pz, sx, sy, sz);
+        if (G > 3 && g == 3) skip_pick<(G > 3 ? 3 * SG : 0), (G > 3 ? 4 * SG : SG)>(ws + 3 * SG, wl, px, py, pz, sx, sy, sz);
+        cg_x[g] = sx; cg_y[g] = sy; cg_z[g] = sz;
       }
-      const float wmax = d6_wave_max(best);
-      const unsigned long long tie = __ballot(best == wmax);
-      int wl = __builtin_ctzll(tie);
-      if (__popcll(tie) != 1) wl = min_key_lane(tie, (int)korig[h * SLOTS + bs], log2s);
-      const int ws = d6_readlane_i(bs, wl);
-      cw_val = wmax;
-      cw_k = (int)korig[(wave * 64 + wl) * SLOTS + ws];
-      skip_pick<0, SLOTS>(ws, wl, px, py, pz, cw_x, cw_y, cw_z);
     }
-    // 2. block arg-max over the waves' cached maxima
+    // 2. the wave's best group (uniform; equal values: the reference's tie key decides)
+    float cw_val = cg_val[0], cw_x = cg_x[0], cw_y = cg_y[0], cw_z = cg_z[0];
+    int cw_k = cg_k[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) {
+      const bool better = cg_val[g] > cw_val || (cg_val[g] == cw_val && tie_key(cg_k[g], log2s) < tie_key(cw_k, log2s));
+      if (better) { cw_val = cg_val[g]; cw_k = cg_k[g]; cw_x = cg_x[g]; cw_y = cg_y[g]; cw_z = cg_z[g]; }
+    }
+    // 3. block arg-max over the waves' cached maxima
     CellSlot *sl = slots[r & 1];
     if (lane == 0) {
       sl[wave].val = cw_val;
@@ -402,14 +430,25 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   static const int skip = getenv("DET6D_FPS_SKIP") ? atoi(getenv("DET6D_FPS_SKIP")) : 16;
   if (skip && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    if (skip != 8) {
-      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<16, 16>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, xyz, perm, idx);
-    } else {
+    // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two
+    // boxes (8-slot groups) per wave (1.08: the second box test and reduction cost more than the shorter scans
+    // save); 8 = 8 waves x 32 slots (1.15); 84 = 8 x 32 in four 8-slot groups (1.36)
+    if (skip == 8) {
       hipLaunchKernelGGL(skip_group_order_kernel<32>, dim3(1, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<8, 32>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, xyz, perm, idx);
+      hipLaunchKernelGGL((fps_skip_kernel<8, 32, 1>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, dbg, xyz, perm, idx);
+    } else if (skip == 84) {
+      hipLaunchKernelGGL(skip_group_order_kernel<8>, dim3(4, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<8, 32, 4>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, dbg, xyz, perm, idx);
+    } else if (skip != 162) {
+      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, dbg, xyz, perm, idx);
+    } else {
+      hipLaunchKernelGGL(skip_group_order_kernel<8>, dim3(4, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 2>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, dbg, xyz, perm, idx);
     }
     return det6d_check_launch("det6d_fps (wave skip)");
   }

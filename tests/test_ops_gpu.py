@@ -327,7 +327,7 @@ def test_fused_sampler_and_helpers(ext, oracle_ops):
     np.testing.assert_array_equal(xyz2.cpu().numpy(), oxyz2)
 
 
-@pytest.mark.parametrize("skip", ["16", "8", "0"])
+@pytest.mark.parametrize("skip", ["16", "162", "8", "0"])
 def test_pruned_fps_kernels_are_exact(skip):
     """fps_cells.hip: the wave-skip sampler (default for 16384 points: 16 waves x 16 slots; 8 x 32 variant) and
     the cell sampler (DET6D_FPS_SKIP=0 + DET6D_FPS_CELLS_MIN_N) must give the oracle's picks bit for bit,
