@@ -297,7 +297,8 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
                                                            const int *__restrict__ perm, int *__restrict__ idxs) {
   constexpr int SG = SLOTS / G, HG = SG / 2;
   static_assert(SG * G == SLOTS && SG % 2 == 0, "group layout");
-  __shared__ CellSlot slots[2][NW];
+  __shared__ float4 slot_v[2][NW];   // (max, x, y, z) of every wave, double buffered by round parity
+  __shared__ int slot_k[2][NW];
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
   xyz += (size_t)blockIdx.x * xyz_bstride;
@@ -394,19 +395,17 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
       if (better) { cw_val = cg_val[g]; cw_k = cg_k[g]; cw_x = cg_x[g]; cw_y = cg_y[g]; cw_z = cg_z[g]; }
     }
     // 3. block arg-max over the waves' cached maxima
-    CellSlot *sl = slots[r & 1];
     if (lane == 0) {
-      sl[wave].val = cw_val;
-      sl[wave].idx = cw_k;
-      sl[wave].x = cw_x; sl[wave].y = cw_y; sl[wave].z = cw_z;
+      slot_v[r & 1][wave] = make_float4(cw_val, cw_x, cw_y, cw_z);   // one ds_write_b128 + one ds_write_b32
+      slot_k[r & 1][wave] = cw_k;
     }
     __syncthreads();
-    const int src = lane & (NW - 1);
-    const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
-    const int i2 = sl[src].idx;
-    const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
-    const float bmax = d6_wave_max(v2);
-    const unsigned long long tie2 = __ballot(v2 == bmax);
+    const int src = lane & (NW - 1);          // every 16-lane row holds all NW <= 16 entries
+    const float4 e2 = slot_v[r & 1][src];
+    const int i2 = slot_k[r & 1][src];
+    const float v2 = e2.x, x2 = e2.y, y2 = e2.z, z2 = e2.w;
+    const float bmax = d6_row_max16(v2);      // 4 DPP steps instead of the 6 of a full-wave maximum
+    const unsigned long long tie2 = __ballot(v2 == bmax) & ((1ull << NW) - 1ull);
     int ww = __builtin_ctzll(tie2);
     if (__popcll(tie2) != 1) ww = min_key_lane(tie2, i2, log2s);
     const int old = d6_readlane_i(i2, ww);
