@@ -28,10 +28,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float relu_act(float v, int act) { return act == 1 ? (v > 0.f ? v : 0.f) : v; }
 
 // BK: k-tile depth (16 or 32).  NBUF = 2 double-buffers the LDS tiles (one barrier per iteration).
-// Measured on MI355X (65536 x 512 x 1024, random data): BK=16/NBUF=1 96 TF, BK=16/NBUF=2 94, BK=32 82-89
-// (occupancy drops from 3 to 2 waves/SIMD), s_setprio around the MFMAs 93.  A timing-only ablation
-// without global loads, LDS stores and barriers (pure ds_read + MFMA loop) reaches 112-115 TF: that
-// is what the chip sustains under this load (DVFS), so the shipped kernel sits at 83-95 % of it.
+// Both were measured again after the vector-ALU clean-up (same-call A/B on MI355X):
+// BK = 32: 582 vs 539 us on 65536 x 512 x 1024; NBUF = 2: GEMM family 1.873 vs 1.840 ms.  Kept as knobs.
+// The bare LDS-fed MFMA loop (scripts/hiptests/lds_mfma.hip) reaches 138-155 TF depending on the box; the
+// largest layer runs at 123-129 TF in the model.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // FAST: the steady-state slabs are fetched with buffer_load_dwordx4 from per-thread byte offsets computed once
