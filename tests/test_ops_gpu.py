@@ -343,6 +343,18 @@ def test_pruned_fps_kernels_are_exact(skip):
     assert len(lines) == 7 and all("exact=True" in l or "exact True" in l for l in lines), out.stdout
 
 
+def test_skip_sampler_on_adversarial_clouds():
+    """wave-skip sampler: more seeds, a lattice with thousands of exact distance ties, collinear points, far
+    outliers — always the oracle's indices"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fps_stress.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALL True" in out.stdout, out.stdout
+
+
 def test_ball_query_grid_adversarial(ext, oracle_ops):
     """grid search corner cases: centres outside the cloud, everything in one cell, outliers that stretch
     the bounding box past 128 cells, vertical stacks (the grid is 2-D), non-finite points"""
