@@ -228,6 +228,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
     for (int ks = 0; ks < nks; ++ks) kstep(As_all + buf * BK * LDA_S, Bs_all + buf * BK * BN, ks);
   };
 
+  // empty-ball counts of the groups this wave pools (pooled layers): fetched now, consumed in the epilogue
+  int pre_cnt[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) pre_cnt[i][qq] = 1;
+  if (FAST_EPI && g.pool != 0 && g.cnt && row0 + BM <= R) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = __builtin_amdgcn_readfirstlane(row0 + (tid >> 6) / WNW * 32 * TM + 32 * i);   // wave-uniform
+      const int ngrp = 32 / g.pool;
+      for (int qq = 0; qq < 4; ++qq)
+        if (qq < ngrp) pre_cnt[i][qq] = g.cnt[rbase / g.pool + qq];
+    }
+  }
   if (FAST && BK <= K) {
     // slab 0 through the fast loader too; grouped_xyz -= new_xyz touches the first float4 of each row only
     const int soff0 = 0;
@@ -324,6 +339,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
           for (int e = 0; e < 16; ++e)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][e] + sh), srd_y, voff,
                                                   ((e & 3) + 8 * (e >> 2)) * ldy4, 0);
+        }
+      }
+    }
+    return;
+  }
+  // interior tiles of pooled layers (the last layer of every SA group, 45 % of the GEMM time): the empty-ball
+  // counts were fetched before the K loop, the lane^32 exchange is one v_permlane32_swap + one v_max, stores go
+  // through the buffer path with the group row as a scalar offset, no bound predicates
+  if (FAST_EPI && g.pool != 0 && row0 + BM <= R && colb + BN <= N) {
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)g.y, 0, 0xffffffff, 0x00020000);
+    const int ldy4 = g.ldy * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colb + wn * 32 * TN + 32 * j + l31;
+      const float sh = g.shift ? g.shift[col] : 0.f;
+      const uint32_t voff = (uint32_t)(g.col0 + col) * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float q[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float lo = d6_vmax(d6_vmax(acc[i][j][4 * qq], acc[i][j][4 * qq + 1]), d6_vmax(acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]));
+          float hi = lo;
+          // lo' = [lo.lanes0-31 | hi.lanes0-31], hi' = [lo.lanes32-63 | hi.lanes32-63]: max(lo', hi') is the 8-row maximum in BOTH halves
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+          q[qq] = d6_vmax(lo, hi);
+        }
+        const int rbase = row0 + wm * 32 * TM + 32 * i;
+        if (g.pool == 32) {
+          const float m = relu_act(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh, g.act);
+          const float v = pre_cnt[i][0] > 0 ? m : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_y, voff, (rbase / 32) * ldy4, 0);
+        } else if (g.pool == 16) {
+          const float m0 = relu_act(d6_vmax(q[0], q[1]) + sh, g.act), m1 = relu_act(d6_vmax(q[2], q[3]) + sh, g.act);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pre_cnt[i][0] > 0 ? m0 : 0.f), srd_y, voff,
+                                                (rbase / 16) * ldy4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pre_cnt[i][1] > 0 ? m1 : 0.f), srd_y, voff,
+                                                (rbase / 16 + 1) * ldy4, 0);
+        } else {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const float m = relu_act(q[qq] + sh, g.act);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pre_cnt[i][qq] > 0 ? m : 0.f), srd_y, voff,
+                                                  (rbase / 8 + qq) * ldy4, 0);
+          }
         }
       }
     }
