@@ -50,4 +50,4 @@ if which == 'nosmall':
         if name == 'det6d_linear' and args[0]._obj.rows <= 8192: return 0
         return _orig(name, *args)
     F.L.call = call
-measure(which)
+measure(which, depth=int(sys.argv[2]) if len(sys.argv) > 2 else 24)
