@@ -22,9 +22,10 @@ import sys
 import time
 
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, the
-# passes kept in flight serialise 4-wide.  Measured on MI355X (24 streams): 4 queues 2051 scenes/s,
-# 8 -> 2039, 16 -> 2929, 32 -> 2482.  Must be set before the HIP runtime initialises.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# passes kept in flight serialise 4-wide.  Measured on MI355X: early in the round (24 streams) 4 queues 2051
+# scenes/s, 8 -> 2039, 16 -> 2929, 32 -> 2482; with the final kernels and linear (fork-free) graphs 16 queues /
+# 15 streams 4372, 20 / 18 4465, 24 / 22 4549, 32 / 24 4434.  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -198,7 +199,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=15, help='passes in flight (15 on 16 hardware queues measured best: 8 -> 3395, 12 -> 3900, 14 -> 4005, 15 -> 4050, 16 -> 3670, 24 -> 3800 scenes/s)')
+    ap.add_argument('--streams', type=int, default=22, help='passes in flight; keep it below GPU_MAX_HW_QUEUES - 1 (24 queues: 18 -> 4454, 20 -> 4500, 22 -> 4549, 23 -> 4434 scenes/s; 16 queues: 15 -> 4372)')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
