@@ -31,7 +31,8 @@ class LinearArgs(ctypes.Structure):
                 ("idx", c_void_p),
                 ("ctr", c_void_p), ("ldctr", c_int),
                 ("pool", c_int),
-                ("cnt", c_void_p)]
+                ("cnt", c_void_p),
+                ("hdr", c_void_p), ("crow_p", c_void_p), ("crow_c", c_void_p)]
 
 
 _P = c_void_p
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "det6d_linear": [ctypes.POINTER(LinearArgs), _P],
     "det6d_mlp_chain3": [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
                          _P, c_int, _P, c_int, _P, c_int, c_int, _P],
+    "det6d_compact_groups": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],
     "det6d_vote_points": [c_int, _P, c_int, _P, c_int, c_float, c_float, c_float, _P, c_int, _P, _P],
     "det6d_decode_boxes": [c_int, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P, _P],
@@ -93,7 +95,8 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
                                                   "det6d_postprocess_workspace_bytes",
                                                   "det6d_ball_query_grid_workspace_bytes",
-                                                  "det6d_prepare_points_workspace_bytes"])
+                                                  "det6d_prepare_points_workspace_bytes",
+                                                  "det6d_compact_rows_capacity"])
 
 _lib = None
 
@@ -119,6 +122,8 @@ def lib():
         handle.det6d_ball_query_grid_workspace_bytes.restype = c_int64
         handle.det6d_prepare_points_workspace_bytes.argtypes = [c_int, c_int]
         handle.det6d_prepare_points_workspace_bytes.restype = c_int64
+        handle.det6d_compact_rows_capacity.argtypes = [c_int, c_int]
+        handle.det6d_compact_rows_capacity.restype = c_int
         handle.det6d_postprocess_workspace_bytes.argtypes = [c_int]
         handle.det6d_postprocess_workspace_bytes.restype = c_int64
         _lib = handle

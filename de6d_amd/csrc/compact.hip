@@ -1,0 +1,140 @@
+// compact.hip — ragged ("compact") row lists for the grouped SA MLPs.
+//
+// The reference materialises nsample rows per centre and pads a ball that holds cnt < nsample points by
+// repeating its first cnt hits (ball_query_gpu.cu:75-90,114-129: `for l = 0; cnt < nsample; ++l, ++cnt:
+// idx[cnt] = idx[l]`); the grouped MLP (pointnet2_modules.py:462-467) is a pointwise function of a row
+// followed by a max over the nsample rows.  Rows >= cnt are therefore exact duplicates of rows < cnt, and
+//     max over nsample rows  ==  max over the first s rows        for every s with cnt <= s <= nsample,
+// bit for bit.  On FPS-sampled clouds most balls are far from full (mean cnt 1..10 of 16 / 32), so the MLP
+// is evaluated on the first s = 2^ceil(log2(cnt)) slots of each centre only (s >= smin; empty balls take
+// the smallest class: their rows are computed from the reference's idx = 0 and masked to zero as before).
+//
+// Row space: centres are binned by class s in {32, 16, 8, 4, 2, 1}; each class owns one contiguous region
+// of the compact row space, the classes in descending s, every region padded to a multiple of 128 rows
+// (one GEMM row tile holds a single class), centres in ascending order inside a region.
+//   hdr[0]      total rows (multiple of 128): the GEMMs read their row count HERE, on the device
+//   hdr[1 + c]  end of the region of class c (s = 32 >> c), c = 0..5;  hdr[6] == hdr[0]
+//   hdr[8]      sum of min(cnt, ns) (rows that carry information), hdr[9] rows before the 128-row alignment
+//   crow_p[r]   global point row (scene * n + neighbour index) row r gathers
+//   crow_c[r]   centre (scene * m + j) row r belongs to, -1 for alignment rows (computed, never stored)
+#include "common.h"
+
+namespace {
+
+constexpr int kClasses = 6;
+
+__device__ __forceinline__ int class_of(int cnt, int ns, int smin) {   // class index c, s = 32 >> c
+  int s = smin;
+  while (s < cnt && s < ns) s <<= 1;
+  return 5 - (31 - __builtin_clz(s));   // s = 32 -> 0 ... s = 1 -> 5
+}
+
+__global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, int m, int ns, int smin, const int *__restrict__ cnt,
+                                                             const int *__restrict__ idx, int *__restrict__ hdr,
+                                                             int *__restrict__ crow_p, int *__restrict__ crow_c) {
+  __shared__ int h_all[kClasses], h_before[kClasses], h_real;
+  __shared__ int wave_cnt[4][kClasses];
+  __shared__ int start[kClasses + 1], base[kClasses];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (((total + gridDim.x - 1) / gridDim.x) + 255) & ~255;
+  const int c_lo = blockIdx.x * chunk;
+  const int c_hi = c_lo + chunk < total ? c_lo + chunk : total;
+  if (tid < kClasses) { h_all[tid] = 0; h_before[tid] = 0; }
+  if (tid == 0) h_real = 0;
+  __syncthreads();
+  {   // class histogram of the whole batch and of the centres before this workgroup's chunk
+    int la[kClasses], lb[kClasses], real = 0;
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) la[c] = lb[c] = 0;
+    for (int i = tid; i < total; i += 256) {
+      const int k = cnt[i];
+      const int c = class_of(k, ns, smin);
+      real += k < ns ? k : ns;
+#pragma unroll
+      for (int cc = 0; cc < kClasses; ++cc) {
+        la[cc] += c == cc;
+        lb[cc] += (c == cc) & (i < c_lo);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+      if (la[c]) atomicAdd(&h_all[c], la[c]);
+      if (lb[c]) atomicAdd(&h_before[c], lb[c]);
+    }
+    if (blockIdx.x == 0 && real) atomicAdd(&h_real, real);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int r = 0, unaligned = 0;
+    for (int c = 0; c < kClasses; ++c) {
+      start[c] = r;
+      base[c] = r + h_before[c] * (32 >> c);
+      unaligned += h_all[c] * (32 >> c);
+      r = (r + h_all[c] * (32 >> c) + 127) & ~127;
+    }
+    start[kClasses] = r;
+    if (blockIdx.x == 0) {
+      hdr[0] = r;
+      for (int c = 0; c < kClasses; ++c) hdr[1 + c] = c + 1 < kClasses ? start[c + 1] : r;
+      hdr[7] = total;
+      hdr[8] = h_real;
+      hdr[9] = unaligned;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {   // alignment rows at the end of every region
+    for (int c = 0; c < kClasses; ++c) {
+      const int e = start[c] + h_all[c] * (32 >> c);
+      for (int r = e + tid; r < start[c + 1]; r += 256) { crow_p[r] = 0; crow_c[r] = -1; }
+    }
+  }
+  // ---- ordered placement of this chunk, 256 centres at a time ----
+  for (int i0 = c_lo; i0 < c_hi; i0 += 256) {
+    const int i = i0 + tid;
+    const bool ok = i < c_hi;
+    const int c = ok ? class_of(cnt[i], ns, smin) : -1;
+    int rank = 0;
+#pragma unroll
+    for (int cc = 0; cc < kClasses; ++cc) {
+      const unsigned long long mk = __ballot(c == cc);
+      if (c == cc) rank = __popcll(mk & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wave][cc] = __popcll(mk);
+    }
+    __syncthreads();
+    if (ok) {
+      int before = 0;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w][c];
+      const int s = 32 >> c;
+      const int r0 = base[c] + (before + rank) * s;
+      const int prow = (i / m) * n;
+      const int *src = idx + (size_t)i * ns;
+      for (int t = 0; t < s; ++t) {
+        crow_p[r0 + t] = prow + src[t];
+        crow_c[r0 + t] = i;
+      }
+    }
+    __syncthreads();
+    if (tid < kClasses) base[tid] += (wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]) * (32 >> tid);
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
+  return (total_centres * ns + kClasses * 128 + 1023) & ~1023;   // a multiple of 8 row tiles: keeps the XCD-aware tile order
+}
+
+DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, const int *cnt, const int *idx, int *hdr,
+                                   int *crow_p, int *crow_c, det6d_stream_t stream) {
+  if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
+  if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
+  if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
+  const int total = b * m;
+  int blocks = det6d_divup(total, 1024);
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, cnt, idx,
+                     hdr, crow_p, crow_c);
+  return det6d_check_launch("det6d_compact_groups");
+}

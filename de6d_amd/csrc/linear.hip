@@ -56,11 +56,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WNW, wn = wave % WNW;
-  const int R = g.rows, K = g.k, N = g.ncols;
+  const int K = g.k, N = g.ncols;
+  // compact (ragged) rows: the row count lives on the device (csrc/compact.hip), g.rows is the capacity the
+  // grid was sized for; tiles past the live rows leave at once.  R is a multiple of 128 there.
+  const int R = g.hdr ? g.hdr[0] : g.rows;
   // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs, each with its
   // own L2.  All column tiles of a row tile get consecutive slots on ONE XCD, so the A rows they share
   // are fetched into that L2 once instead of once per column tile (speed only, never correctness).
-  const int gm = (R + BM - 1) / BM, gn = (N + BN - 1) / BN;
+  const int gm = (g.rows + BM - 1) / BM, gn = (N + BN - 1) / BN;
   int row_tile, col_tile;
   if (gn > 1 && (gm & 7) == 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -72,6 +75,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   }
   const int row0 = row_tile * BM;
   const int colb = col_tile * BN;
+  if (row0 >= R) return;
+  // pooling width of this tile: fixed (dense rows) or the class of the compact region the tile lies in
+  int pool = g.pool;
+  if (pool < 0)
+    pool = row0 < g.hdr[1] ? 32 : row0 < g.hdr[2] ? 16 : row0 < g.hdr[3] ? 8 : row0 < g.hdr[4] ? 4 : row0 < g.hdr[5] ? 2 : 1;
 
   // ---- A loader: each thread owns rows (tid/4) [and (tid/4 + 64)], k-quad (tid%4) of the tile ----
   const int ar = tid >> 2, akq = tid & 3;
@@ -92,6 +100,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         const int p = g.idx[r];
         arow[i] = g.a + ((size_t)bi * g.n + p) * g.lda;
         if (akq == 0) {
+          const float *c = g.ctr + (size_t)cj * g.ldctr;
+          csub[i][0] = c[0]; csub[i][1] = c[1]; csub[i][2] = c[2];
+        }
+      } else if (g.mode == DET6D_A_COMPACT) {
+        arow[i] = g.a + (size_t)g.crow_p[r] * g.lda;
+        const int cj = g.crow_c[r];
+        if (akq == 0 && cj >= 0) {
           const float *c = g.ctr + (size_t)cj * g.ldctr;
           csub[i][0] = c[0]; csub[i][1] = c[1]; csub[i][2] = c[2];
         }
@@ -234,13 +249,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) pre_cnt[i][qq] = 1;
-  if (FAST_EPI && g.pool != 0 && g.cnt && row0 + BM <= R) {
+  if (FAST_EPI && g.pool > 0 && g.cnt && row0 + BM <= R) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = __builtin_amdgcn_readfirstlane(row0 + (tid >> 6) / WNW * 32 * TM + 32 * i);   // wave-uniform
       const int ngrp = 32 / g.pool;
       for (int qq = 0; qq < 4; ++qq)
         if (qq < ngrp) pre_cnt[i][qq] = g.cnt[rbase / g.pool + qq];
+    }
+  }
+  // compact rows: the centre each of this lane's (up to four) pooled values belongs to, -1 = nothing to store
+  // (alignment rows, or another lane is the writer).  Rows of a 32x32 tile held by a lane: 8*qq + 4*kh + (0..3).
+  //   class 4: group = rows 8*qq + 4*kh .. +3, every lane writes its own four groups
+  //   class 8 / 16 / 32: the lane^32 exchange completes the group; lanes of half 0 write group qq / qq>>1 / 0
+  int pre_ctr[TM][4];
+  if (g.pool < 0) {
+    const int khl = (tid & 63) >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = row0 + wm * 32 * TM + 32 * i;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int rsel = pool == 4 ? 8 * qq + 4 * khl : pool == 8 ? 8 * qq : pool == 16 ? 16 * (qq >> 1) : 0;
+        const bool writer = pool == 4 || (khl == 0 && (pool == 8 || (pool == 16 && !(qq & 1)) || (pool == 32 && qq == 0)));
+        int cj = -1;
+        if (writer) cj = g.crow_c[rbase + rsel];
+        pre_ctr[i][qq] = cj;
+        pre_cnt[i][qq] = (cj >= 0 && g.cnt) ? g.cnt[cj] : 1;
+      }
     }
   }
   if (FAST && BK <= K) {
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
       const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff_b[i], soff0, 0));
       rb[i] = make_float4(v.x, v.y, v.z, v.w);
     }
-    if (g.mode == DET6D_A_GROUPED && akq == 0) {
+    if (g.mode != DET6D_A_ROWS && akq == 0) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         ra[i][0].x = ra[i][0].x - csub[i][0]; ra[i][0].y = ra[i][0].y - csub[i][1]; ra[i][0].z = ra[i][0].z - csub[i][2];
@@ -347,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   // interior tiles of pooled layers (the last layer of every SA group, 45 % of the GEMM time): the empty-ball
   // counts were fetched before the K loop, the lane^32 exchange is one v_permlane32_swap + one v_max, stores go
   // through the buffer path with the group row as a scalar offset, no bound predicates
-  if (FAST_EPI && g.pool != 0 && row0 + BM <= R && colb + BN <= N) {
+  if (FAST_EPI && g.pool > 0 && row0 + BM <= R && colb + BN <= N) {
     const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)g.y, 0, 0xffffffff, 0x00020000);
     const int ldy4 = g.ldy * 4;
 #pragma unroll
@@ -384,6 +420,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pre_cnt[i][qq] > 0 ? m : 0.f), srd_y, voff,
                                                   (rbase / 8 + qq) * ldy4, 0);
           }
+        }
+      }
+    }
+    return;
+  }
+  // compact rows, pooled layer: segment maxima by class, scattered to the rows of their centres
+  if (g.pool < 0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colb + wn * 32 * TN + 32 * j + l31;
+      const bool cok = col < N;
+      const float sh = (cok && g.shift) ? g.shift[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          v[qq] = d6_vmax(d6_vmax(acc[i][j][4 * qq], acc[i][j][4 * qq + 1]), d6_vmax(acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]));
+        if (pool > 4) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            float lo = v[qq], hi = v[qq];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+            v[qq] = d6_vmax(lo, hi);
+          }
+          if (pool == 16) {
+            v[0] = d6_vmax(v[0], v[1]);
+            v[2] = d6_vmax(v[2], v[3]);
+          } else if (pool == 32) {
+            v[0] = d6_vmax(d6_vmax(v[0], v[1]), d6_vmax(v[2], v[3]));
+          }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int cj = pre_ctr[i][qq];
+          if (cok && cj >= 0)
+            g.y[(size_t)cj * g.ldy + g.col0 + col] = pre_cnt[i][qq] > 0 ? relu_act(v[qq] + sh, g.act) : 0.f;
         }
       }
     }
@@ -459,16 +532,24 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   if (a->mode == DET6D_A_GROUPED) {
     if (!a->idx || !a->ctr || a->ns <= 0 || a->m <= 0 || a->n <= 0 || a->ldctr < 3) return DET6D_EINVAL;
     if (a->rows % (a->m * a->ns)) return DET6D_EINVAL;
+  } else if (a->mode == DET6D_A_COMPACT) {
+    if (!a->hdr || !a->crow_p || !a->crow_c || !a->ctr || a->n <= 0 || a->ldctr < 3) return DET6D_EINVAL;
   } else if (a->mode != DET6D_A_ROWS) {
     return DET6D_EINVAL;
   }
-  if (a->pool != 0 && a->pool != 8 && a->pool != 16 && a->pool != 32) return DET6D_EINVAL;
-  if (a->pool && (a->rows % a->pool)) return DET6D_EINVAL;
+  if (a->pool < 0) {   // class pooling over compact rows
+    if (!a->hdr || !a->crow_c) return DET6D_EINVAL;
+  } else {
+    if (a->pool != 0 && a->pool != 8 && a->pool != 16 && a->pool != 32) return DET6D_EINVAL;
+    if (a->pool && (a->rows % a->pool)) return DET6D_EINVAL;
+  }
+  if (a->hdr && (a->rows & 127)) return DET6D_EINVAL;   // capacity of a compact row space (det6d_compact_rows_capacity)
   if (a->rows == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
   const int gm = det6d_divup(a->rows, 128);
   // the buffer-load fast path addresses A and W with 32-bit byte offsets
-  const size_t a_rows = a->mode == DET6D_A_GROUPED ? (size_t)(a->rows / (a->m * a->ns)) * a->n : (size_t)a->rows;
+  const size_t a_rows = a->mode == DET6D_A_GROUPED ? (size_t)(a->rows / (a->m * a->ns)) * a->n
+                        : a->mode == DET6D_A_COMPACT ? (size_t)a->n : (size_t)a->rows;
   const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull &&
                       (size_t)a->rows * a->ldy * 4 < 0xfff00000ull;
   static const bool no_fast = getenv("DET6D_LINEAR_NO_FAST") != nullptr;

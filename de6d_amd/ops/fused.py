@@ -62,12 +62,41 @@ def gather_rows(rows_in, idx, ncol, out):
     return out
 
 
-def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None, cnt=None, pool=0):
+class CompactRows:
+    """compact (ragged) row list of one radius group (csrc/compact.hip): only the first
+    s = max(smin, 2^ceil(log2 cnt)) slots of every centre are MLP rows; identical pooled features."""
+    __slots__ = ('hdr', 'crow_p', 'crow_c', 'capacity', 'ns')
+
+    def __init__(self, hdr, crow_p, crow_c, capacity, ns):
+        self.hdr, self.crow_p, self.crow_c, self.capacity, self.ns = hdr, crow_p, crow_c, capacity, ns
+
+
+#: smallest row class of the compact lists
+COMPACT_SMIN = int(os.environ.get('DET6D_COMPACT_SMIN', '4'))
+
+
+def compact_groups(cnt, idx, n):
+    """cnt (B,m), idx (B,m,ns) from a ball query over n points per scene -> CompactRows"""
+    L.require_cuda(cnt, idx)
+    b, m, ns = idx.shape
+    cap = int(L.lib().det6d_compact_rows_capacity(b * m, ns))
+    hdr = torch.empty((16,), dtype=torch.int32, device=idx.device)
+    crow_p = torch.empty((cap,), dtype=torch.int32, device=idx.device)
+    crow_c = torch.empty((cap,), dtype=torch.int32, device=idx.device)
+    L.call("det6d_compact_groups", b, n, m, ns, min(COMPACT_SMIN, ns), L.ptr(cnt), L.ptr(idx), L.ptr(hdr), L.ptr(crow_p),
+           L.ptr(crow_c), L.stream_ptr())
+    return CompactRows(hdr, crow_p, crow_c, cap, ns)
+
+
+def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None, cnt=None, pool=0, compact=None,
+           gather=False):
     """out[..., col0:col0+ncols] = act(A' @ W + shift) with optional neighbour gather / max-pool.
 
     a:   (R, lda) rows, or (B, n, lda) point rows when `idx` (B, m, ns) is given
     w:   (K_rows, ldw) weights, BN folded;  shift: (ncols,) or None;  act: 0 none / 1 ReLU
     out: (R or R/pool, ldy)
+    compact: CompactRows -> the rows are the compact list's (live count read on the device); with `gather` the
+         A' rows are gathered through it from the point rows `a` (B, n, lda) and `ctr`; pool = -1 pools by class
     """
     L.require_cuda(a, w, shift, out, idx, ctr, cnt)
     g = L.LinearArgs()
@@ -78,7 +107,17 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
     g.shift = shift.data_ptr() if shift is not None else None
     g.act = act
     g.y, g.ldy, g.col0 = out.data_ptr(), out.shape[-1], col0
-    if idx is not None:
+    if compact is not None:
+        g.hdr, g.crow_p, g.crow_c = compact.hdr.data_ptr(), compact.crow_p.data_ptr(), compact.crow_c.data_ptr()
+        g.rows = compact.capacity
+        if gather:
+            g.mode = 2
+            g.n = a.shape[0] * a.shape[1]
+            g.ctr, g.ldctr = ctr.data_ptr(), ctr.shape[-1]
+        else:
+            g.mode = 0
+            assert a.numel() // a.shape[-1] >= compact.capacity
+    elif idx is not None:
         bsz, m, ns = idx.shape
         g.mode, g.rows = 1, bsz * m * ns
         g.n, g.m, g.ns = a.shape[1], m, ns
@@ -93,7 +132,7 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
         e0.record()
         L.call("det6d_linear", ctypes.byref(g), L.stream_ptr())
         e1.record()
-        LINEAR_EVENTS.append((e0, e1, g.rows, g.k, g.ncols))
+        LINEAR_EVENTS.append((e0, e1, g.rows if compact is None else compact.hdr, g.k, g.ncols))
         return out
     L.call("det6d_linear", ctypes.byref(g), L.stream_ptr())
     return out

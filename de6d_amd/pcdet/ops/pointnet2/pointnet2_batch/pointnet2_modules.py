@@ -104,6 +104,12 @@ def run_chain(x, layers, out=None, col0=0):
 #: (4121 vs 4300 scenes/s at 15 passes: more sampler workgroups resident at once, fork/join in every graph).
 SEQUENTIAL_SAMPLERS = os.environ.get('DET6D_FORKED_SAMPLERS') is None
 
+#: Grouped MLPs run on compact (ragged) row lists: a ball with cnt < nsample hits is padded by the reference with
+#: repetitions of its first cnt hits, so only the first 2^ceil(log2 cnt) slots of a centre are evaluated — the
+#: pooled features are identical bit for bit (csrc/compact.hip).  DET6D_DENSE_ROWS=1 restores the reference's
+#: dense (B, m, nsample) row space.
+COMPACT_ROWS = os.environ.get('DET6D_DENSE_ROWS') is None
+
 
 class _PointnetSAModuleFSBase(nn.Module):
     def __init__(self):
@@ -231,6 +237,24 @@ class _PointnetSAModuleFSBase(nn.Module):
                     pn2.ball_query_cnt_wrapper(b, n, m, rout, nsample, new_xyz, xyz, idx_cnt, idx)
                 found.append((idx_cnt, idx))
         for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
+            if COMPACT_ROWS and nsample in (4, 8, 16, 32):
+                cr = fused.compact_groups(idx_cnt, idx, n)
+                x = None
+                for li, (w, shift, cout, act) in enumerate(layers):
+                    if li == len(layers) - 1:
+                        tgt, kw = pooled, dict(ncols=cout, col0=col, cnt=idx_cnt, pool=-1)
+                    else:
+                        tgt = torch.empty((cr.capacity, w.shape[1]), dtype=torch.float32, device=rows.device)
+                        if w.shape[1] != cout:
+                            tgt[:, cout:].zero_()
+                        kw = dict(ncols=cout)
+                    if li == 0:
+                        fused.linear(rows, w, shift, act, tgt, ctr=new_xyz, compact=cr, gather=True, **kw)
+                    else:
+                        fused.linear(x, w, shift, act, tgt, compact=cr, **kw)
+                    x = tgt
+                col += layers[-1][2]
+                continue
             if fused.chain_eligible(rows.shape[-1], layers, nsample):   # narrow group: one fused launch
                 fused.mlp_chain3(rows, idx, new_xyz, idx_cnt, layers, pooled, col)
                 col += layers[-1][2]

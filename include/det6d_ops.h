@@ -302,8 +302,9 @@ int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int ncol, cons
  */
 #define DET6D_A_ROWS 0
 #define DET6D_A_GROUPED 1
+#define DET6D_A_COMPACT 2   /* A' rows gathered through a compact row list (det6d_compact_groups) */
 typedef struct det6d_linear_args {
-  int mode;          /* DET6D_A_ROWS / DET6D_A_GROUPED */
+  int mode;          /* DET6D_A_ROWS / DET6D_A_GROUPED / DET6D_A_COMPACT */
   int rows;          /* R: number of A' rows (= b*m*ns in grouped mode) */
   int k;             /* reduction length (columns of A' actually used) */
   int ncols;         /* N: output channels */
@@ -317,10 +318,27 @@ typedef struct det6d_linear_args {
   const int *idx;          /* (B,m,ns) */
   const float *ctr; int ldctr; /* (B,m,ldctr) centre rows, first 3 columns are xyz */
   /* pooling epilogue */
-  int pool;                /* 0 or ns */
+  int pool;                /* 0, or ns (dense rows), or -1: class pooling over compact rows (hdr, crow_c) */
   const int *cnt;          /* (B*m) hit counts or NULL (no mask) */
+  /* compact (ragged) rows, see det6d_compact_groups.  With hdr != NULL the live row count is hdr[0], read on
+   * the DEVICE; `rows` is then the capacity (det6d_compact_rows_capacity) the launch is sized for. */
+  const int *hdr;
+  const int *crow_p;       /* mode COMPACT: point row (scene * n + neighbour) of every compact row; n = B * n */
+  const int *crow_c;       /* mode COMPACT / pool -1: centre (scene * m + j) of every compact row, -1 = padding */
 } det6d_linear_args;
 int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
+
+/* Compact (ragged) row lists for a grouped MLP.  A ball with cnt < nsample hits is padded by the reference
+ * with repetitions of its first cnt hits (ball_query_gpu.cu:75-90,114-129), the MLP is pointwise per row
+ * and is followed by a max over the nsample rows (pointnet2_modules.py:462-467): evaluating only the first
+ * s = max(smin, 2^ceil(log2 cnt)) slots of every centre gives the same pooled features bit for bit.
+ *   cnt (B*m), idx (B,m,ns) as written by the ball queries;  ns, smin powers of two, smin <= ns <= 32;
+ *   hdr (16) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
+ *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment;
+ *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row. */
+int det6d_compact_rows_capacity(int total_centres, int ns);
+int det6d_compact_groups(int b, int n, int m, int ns, int smin, const int *cnt, const int *idx, int *hdr,
+                         int *crow_p, int *crow_c, det6d_stream_t stream);
 
 /* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to
  *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)

@@ -1,7 +1,7 @@
 """what-if throughput experiments (NOT results): replace one stage by a trivial stand-in before the graphs are
 captured and see how the step time moves -> that stage's cost in the 24-passes-in-flight regime"""
 import os, sys, time
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from de6d_amd.runtime import load_config, build_model, GraphedDet6D
