@@ -16,7 +16,8 @@
 //   hdr[1 + c]  end of the region of class c (s = 32 >> c), c = 0..5;  hdr[6] == hdr[0]
 //   hdr[8]      sum of min(cnt, ns) (rows that carry information), hdr[9] rows before the 128-row alignment
 //   crow_p[r]   global point row (scene * n + neighbour index) row r gathers
-//   crow_c[r]   centre (scene * m + j) row r belongs to, -1 for alignment rows (computed, never stored)
+//   crow_c[r]   centre (scene * m + j) row r belongs to, bit 30 set when its ball is empty (pooled value = 0:
+//               pointnet2_modules.py:465-467), -1 for alignment rows (computed, never stored)
 #include "common.h"
 
 namespace {
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
   __shared__ int h_all[kClasses], h_before[kClasses], h_real;
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
+  __shared__ int r0_s[256], cls_s[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = (((total + gridDim.x - 1) / gridDim.x) + 255) & ~255;
   const int c_lo = blockIdx.x * chunk;
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
       for (int r = e + tid; r < start[c + 1]; r += 256) { crow_p[r] = 0; crow_c[r] = -1; }
     }
   }
-  // ---- ordered placement of this chunk, 256 centres at a time ----
+  // ---- ordered placement of this chunk, 256 centres at a time: first row r0 and class of every centre into
+  //      LDS (ballot ranks), then one thread per (centre, slot) so that idx is read and the rows are written
+  //      with consecutive lanes on consecutive words ----
   for (int i0 = c_lo; i0 < c_hi; i0 += 256) {
     const int i = i0 + tid;
     const bool ok = i < c_hi;
@@ -104,17 +108,22 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
     if (ok) {
       int before = 0;
       for (int w = 0; w < wave; ++w) before += wave_cnt[w][c];
-      const int s = 32 >> c;
-      const int r0 = base[c] + (before + rank) * s;
-      const int prow = (i / m) * n;
-      const int *src = idx + (size_t)i * ns;
-      for (int t = 0; t < s; ++t) {
-        crow_p[r0 + t] = prow + src[t];
-        crow_c[r0 + t] = i;
-      }
+      r0_s[tid] = base[c] + (before + rank) * (32 >> c);
+      cls_s[tid] = 32 >> c;
+    } else {
+      cls_s[tid] = 0;
     }
     __syncthreads();
     if (tid < kClasses) base[tid] += (wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]) * (32 >> tid);
+    const int lg = 31 - __builtin_clz(ns);
+    for (int e = tid; e < 256 * ns; e += 256) {
+      const int ci = e >> lg, t = e & (ns - 1);
+      if (t < cls_s[ci]) {
+        const int cg = i0 + ci;
+        crow_p[r0_s[ci] + t] = (cg / m) * n + idx[(size_t)cg * ns + t];
+        crow_c[r0_s[ci] + t] = cnt[cg] > 0 ? cg : (cg | 0x40000000);
+      }
+    }
     __syncthreads();
   }
 }
@@ -131,8 +140,8 @@ DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, const 
   if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
   if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
   const int total = b * m;
-  int blocks = det6d_divup(total, 1024);
-  if (blocks > 64) blocks = 64;
+  int blocks = det6d_divup(total, 256);   // every workgroup reads all counts once (prefix of its chunk): keep them few
+  if (blocks > 128) blocks = 128;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, cnt, idx,
                      hdr, crow_p, crow_c);

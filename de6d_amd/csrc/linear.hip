@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         arow[i] = g.a + (size_t)g.crow_p[r] * g.lda;
         const int cj = g.crow_c[r];
         if (akq == 0 && cj >= 0) {
-          const float *c = g.ctr + (size_t)cj * g.ldctr;
+          const float *c = g.ctr + (size_t)(cj & 0x3fffffff) * g.ldctr;
           csub[i][0] = c[0]; csub[i][1] = c[1]; csub[i][2] = c[2];
         }
       } else {
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         const bool writer = pool == 4 || (khl == 0 && (pool == 8 || (pool == 16 && !(qq & 1)) || (pool == 32 && qq == 0)));
         int cj = -1;
         if (writer) cj = g.crow_c[rbase + rsel];
-        pre_ctr[i][qq] = cj;
-        pre_cnt[i][qq] = (cj >= 0 && g.cnt) ? g.cnt[cj] : 1;
+        pre_ctr[i][qq] = cj < 0 ? -1 : (cj & 0x3fffffff);
+        pre_cnt[i][qq] = (cj & 0x40000000) ? 0 : 1;   // bit 30: empty ball
       }
     }
   }

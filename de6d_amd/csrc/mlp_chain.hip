@@ -42,7 +42,36 @@ struct ChainArgs {
   const float *s1, *s2, *s3;  // shifts
   int k1, c1, c2, c3;         // true widths: k1 = lda, c1,c2 <= 32, c3 <= 64
   float *y; int ldy; int col0;
+  // compact (ragged) rows (csrc/compact.hip): live row count and class regions in hdr, one point row and one
+  // centre per compact row; rows = capacity then
+  const int *hdr; const int *crow_p; const int *crow_c;
 };
+
+// compact rows: class (= pooling width) of the 32-row tile starting at row0; h[c] = end of the region of class 32 >> c
+__device__ __forceinline__ int compact_class(int row0, int h1, int h2, int h3, int h4, int h5) {
+  return row0 < h1 ? 32 : row0 < h2 ? 16 : row0 < h3 ? 8 : row0 < h4 ? 4 : row0 < h5 ? 2 : 1;
+}
+// row (inside a 32-row tile) whose centre owns pooled value qq of a lane in half kh, -1: another lane writes it.
+// A lane holds rows 8*qq + 4*kh + (0..3); class 4 groups end inside the lane, wider groups after the lane^32 exchange.
+__device__ __forceinline__ int compact_out_row(int s, int qq, int kh) {
+  if (s == 4) return 8 * qq + 4 * kh;
+  if (kh) return -1;
+  if (s == 8) return 8 * qq;
+  if (s == 16) return (qq & 1) ? -1 : 8 * qq;
+  return qq == 0 ? 0 : -1;
+}
+// the four 4-row maxima of a lane -> pooled values of class s (in place; v[qq] valid where compact_out_row >= 0)
+__device__ __forceinline__ void compact_pool(float (&v)[4], int s) {
+  if (s == 4) return;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) v[qq] = d6_vmax(v[qq], __shfl_xor(v[qq], 32));
+  if (s == 16) {
+    v[0] = d6_vmax(v[0], v[1]);
+    v[2] = d6_vmax(v[2], v[3]);
+  } else if (s == 32) {
+    v[0] = d6_vmax(d6_vmax(v[0], v[1]), d6_vmax(v[2], v[3]));
+  }
+}
 
 __device__ __forceinline__ float relu1(float v) { return v > 0.f ? v : 0.f; }
 
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
 // orientation (same fragments, operands swapped back) so that the max over the nsample rows is the cheap
 // in-register / one-shuffle epilogue and the store is coalesced.
 // Every output is still ONE ascending-k fma chain: bit-identical to det6d_linear x 3.
-template <int C1, int C2, int C3, int NS>
+template <int C1, int C2, int C3, int NS, bool COMPACT = false>
 __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
   constexpr int S2 = C1 / 2, S3 = C2 / 2, NT3 = C3 / 32;
@@ -225,15 +254,32 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   for (int j = 0; j < NT3; ++j) sh3[j] = g.s3[32 * j + l31];
   const float one_k0 = kh == 0 ? 1.f : 0.f;
 
-  const int ntiles = g.rows / 32;
+  int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+  if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
+  const int ntiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
+  const int *nb_idx = COMPACT ? g.crow_p : g.idx;   // per-row neighbour: point index inside the scene / global point row
   // the tile index is wave-uniform: kept in SGPRs so that the batch index (a division by m) is scalar work
   int tile = __builtin_amdgcn_readfirstlane(wave_global);
   if (tile >= ntiles) return;
   // software pipeline: the neighbour index of the tile after next and the point row of the next tile are in
   // flight while this tile computes (index -> row is a dependent pair of loads)
-  struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; };
+  struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; int oc[4]; };
   auto fetch = [&](int t, int p) {   // t wave-uniform; for NS == 16 the two centres of a tile share the batch (m even)
     TileIn in;
+    if (COMPACT) {
+      in.row = *reinterpret_cast<const float4 *>(g.a + (size_t)p * 4);
+      const int cj = g.crow_c[t * 32 + l31];
+      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x3fffffff) * g.ldctr;
+      in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
+      in.cnt0 = in.cnt1 = 0;
+      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int r = compact_out_row(sc, qq, kh);
+        in.oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
+      }
+      return in;
+    }
     const int c0 = NS == 32 ? t : 2 * t;             // first centre of the tile (scalar)
     const int bi = c0 / g.m;                         // scalar division
     const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
@@ -244,17 +290,22 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     in.cnt1 = NS == 32 ? 0 : g.cnt[c0 + 1];
     return in;
   };
-  TileIn nxt = fetch(tile, g.idx[tile * 32 + l31]);
-  int p_next = tile + n_waves < ntiles ? g.idx[(tile + n_waves) * 32 + l31] : 0;
+  TileIn nxt = fetch(tile, nb_idx[tile * 32 + l31]);
+  int p_next = tile + n_waves < ntiles ? nb_idx[(tile + n_waves) * 32 + l31] : 0;
   // results are stored one iteration late, BEFORE the next prefetch is issued: the wait for the prefetched
   // inputs at the top of an iteration then never waits for this tile's stores (vmcnt counts in order)
-  float pend[NT3][2];
+  float pend[NT3][COMPACT ? 4 : 2];
+  int pend_oc[4] = {-1, -1, -1, -1};
   int pend_tile = -1;
   auto flush = [&]() {
 #pragma unroll
     for (int j = 0; j < NT3; ++j) {
       const int col = 32 * j + l31;
-      if (NS == 32) {
+      if (COMPACT) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (pend_oc[qq] >= 0) g.y[(size_t)(pend_oc[qq] & 0x3fffffff) * g.ldy + g.col0 + col] = pend[j][qq];
+      } else if (NS == 32) {
         g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
       } else {
         g.y[(size_t)(2 * pend_tile) * g.ldy + g.col0 + col] = pend[j][0];
@@ -267,7 +318,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     if (pend_tile >= 0) flush();
     if (tile + n_waves < ntiles) {
       nxt = fetch(tile + n_waves, p_next);
-      if (tile + 2 * n_waves < ntiles) p_next = g.idx[(tile + 2 * n_waves) * 32 + l31];
+      if (tile + 2 * n_waves < ntiles) p_next = nb_idx[(tile + 2 * n_waves) * 32 + l31];
     }
     const float4 v0 = cur.row;
     const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
@@ -317,6 +368,14 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
       const int col = 32 * j + l31;
       // max over the rows on the raw accumulators, shift + ReLU on the pooled value (monotone: same result)
       float q[4];
+      if (COMPACT) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
+        compact_pool(q, compact_class(tile * 32, h1, h2, h3, h4, h5));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) pend[j][qq] = (cur.oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]);
+        continue;
+      }
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const float mq = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
@@ -333,6 +392,10 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
       }
     }
     pend_tile = tile;
+    if (COMPACT) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) pend_oc[qq] = cur.oc[qq];
+    }
   }
   flush();
 }
@@ -346,7 +409,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
 // row never touches LDS either: lane (row, kh) loads x[row][2s + kh] directly, 34 dword loads with
 // immediate offsets, issued for the NEXT tile as soon as layer 1 of the current one has consumed them.
 // Per tile ~250 vector-ALU ops (ReLU, swaps, pooling) against 17-23 k cycles of matrix work.
-template <int C2, int NS>
+template <int C2, int NS, bool COMPACT = false>
 __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) {
   constexpr int K1 = 68, C1 = 64, C3 = 128;
   constexpr int S1 = K1 / 2, S2 = C1 / 2, S3 = C2 / 2;
@@ -377,14 +440,35 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
 
   const float one_k0 = kh == 0 ? 1.f : 0.f;
   const int wave_global = (blockIdx.x * blockDim.x + tid) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  const int ntiles = g.rows / 32;
+  int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+  if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
+  const int ntiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   int tile = __builtin_amdgcn_readfirstlane(wave_global);
   if (tile >= ntiles) return;
 
   float xin[S1];
   float csub0, csub1;
   int cnt0, cnt1;
+  int oc_n[4] = {-1, -1, -1, -1};
   auto fetch = [&](int t) {   // t wave-uniform
+    if (COMPACT) {
+      const int p = g.crow_p[t * 32 + l31];
+      const float *src = g.a + (size_t)p * K1 + kh;
+#pragma unroll
+      for (int s = 0; s < S1; ++s) xin[s] = src[2 * s];
+      const int cj = g.crow_c[t * 32 + l31];
+      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x3fffffff) * g.ldctr;
+      csub0 = kh ? c[1] : c[0];
+      csub1 = kh ? 0.f : c[2];
+      cnt0 = cnt1 = 0;
+      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int r = compact_out_row(sc, qq, kh);
+        oc_n[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
+      }
+      return;
+    }
     const int c0 = NS == 32 ? t : 2 * t;
     const int bi = c0 / g.m;
     const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
@@ -410,13 +494,18 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     }
   };
 
-  float pend[T3][2];
+  float pend[T3][COMPACT ? 4 : 2];
+  int pend_oc[4] = {-1, -1, -1, -1};
   int pend_tile = -1;
   auto flush = [&]() {
 #pragma unroll
     for (int j = 0; j < T3; ++j) {
       const int col = 32 * j + l31;
-      if (NS == 32) {
+      if (COMPACT) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (pend_oc[qq] >= 0) g.y[(size_t)(pend_oc[qq] & 0x3fffffff) * g.ldy + g.col0 + col] = pend[j][qq];
+      } else if (NS == 32) {
         g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
       } else {
         g.y[(size_t)(2 * pend_tile) * g.ldy + g.col0 + col] = pend[j][0];
@@ -429,6 +518,9 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   for (; tile < ntiles; tile += n_waves) {
     if (pend_tile >= 0) flush();
     const int my_cnt0 = cnt0, my_cnt1 = cnt1;
+    int my_oc[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) my_oc[qq] = oc_n[qq];
     xin[0] = xin[0] - csub0;
     xin[1] = xin[1] - csub1;
     // ---- layer 1 (transposed): K1 -> C1 ----
@@ -469,6 +561,14 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       for (int s = 0; s < S3; ++s)
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[s], W3[(2 * s + kh) * C3 + 32 * j + l31], o, 0, 0, 0);
       float q[4];
+      if (COMPACT) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
+        compact_pool(q, compact_class(tile * 32, h1, h2, h3, h4, h5));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) pend[j][qq] = (my_oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]);
+        continue;
+      }
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const float mq = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
@@ -483,6 +583,10 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       }
     }
     pend_tile = tile;
+    if (COMPACT) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) pend_oc[qq] = my_oc[qq];
+    }
   }
   flush();
 }
@@ -514,6 +618,7 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   g.s1 = s1; g.s2 = s2; g.s3 = s3;
   g.k1 = lda; g.c1 = c1; g.c2 = c2; g.c3 = c3;
   g.y = y; g.ldy = ldy; g.col0 = col0;
+  g.hdr = nullptr; g.crow_p = nullptr; g.crow_c = nullptr;
   const int ntiles = rows / 32;
   if (wide) {   // one 512-thread workgroup per CU (weights fill most of its LDS), two waves per SIMD
     const size_t lds_bytes = sizeof(float) * ((size_t)70 * 64 + (size_t)66 * c2 + (size_t)c2 * 128);
@@ -554,4 +659,56 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   else
     hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(64 * kChainWaves), 0, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_chain3");
+}
+
+// The same chains over a compact (ragged) row list: rows, classes and output centres come from det6d_compact_groups
+// (hdr / crow_p / crow_c on the device), `capacity` only sizes the persistent grid.
+DET6D_API int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *crow_p, const int *crow_c, const float *a,
+                                       int lda, const float *ctr, int ldctr, const float *w1, int ldw1, const float *s1,
+                                       int c1, const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
+                                       const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream) {
+  if (capacity <= 0 || (capacity & 127) || !hdr || !crow_p || !crow_c || !a || !ctr || ldctr < 3 || !w1 || !w2 || !w3 || !s1 ||
+      !s2 || !s3 || !y)
+    return DET6D_EINVAL;
+  if (ldw1 < c1 || ldw2 < c2 || ldw3 < c3) return DET6D_EINVAL;
+  const bool wide = lda == 68 && c1 == 64 && (c2 == 64 || c2 == 96) && c3 == 128 && !(ldw1 & 3) && !(ldw2 & 3) && !(ldw3 & 3) &&
+                    !(((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)s1 | (uintptr_t)s2) & 15);
+  const bool narrow = lda == 4 && !((uintptr_t)a & 15) && ((c1 == 16 && c2 == 16 && c3 == 32) || (c1 == 32 && c2 == 32 && c3 == 64));
+  if (!wide && !narrow) return DET6D_EINVAL;
+  ChainArgs g;
+  g.rows = capacity; g.n = 0; g.m = 0; g.ns = 0;
+  g.a = a; g.lda = lda; g.idx = nullptr; g.ctr = ctr; g.ldctr = ldctr; g.cnt = nullptr;
+  g.w1 = w1; g.w2 = w2; g.w3 = w3; g.ldw1 = ldw1; g.ldw2 = ldw2; g.ldw3 = ldw3;
+  g.s1 = s1; g.s2 = s2; g.s3 = s3;
+  g.k1 = lda; g.c1 = c1; g.c2 = c2; g.c3 = c3;
+  g.y = y; g.ldy = ldy; g.col0 = col0;
+  g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
+  const int ntiles = capacity / 32;
+  if (wide) {
+    const size_t lds_bytes = sizeof(float) * ((size_t)70 * 64 + (size_t)66 * c2 + (size_t)c2 * 128);
+    const int wb = det6d_divup(ntiles, 8) < 256 ? det6d_divup(ntiles, 8) : 256;
+    if (c2 == 64) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<64, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((mlp_chain_wide_kernel<64, 32, true>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<96, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((mlp_chain_wide_kernel<96, 32, true>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);
+    }
+    return det6d_check_launch("det6d_mlp_chain3_compact");
+  }
+  int blocks = det6d_divup(ntiles, 4);
+  if (blocks > 1024) blocks = 1024;
+  if (c1 == 16)
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32, 32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL((mlp_chain_reg_kernel<32, 32, 64, 32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  return det6d_check_launch("det6d_mlp_chain3_compact");
 }

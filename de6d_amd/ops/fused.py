@@ -71,8 +71,9 @@ class CompactRows:
         self.hdr, self.crow_p, self.crow_c, self.capacity, self.ns = hdr, crow_p, crow_c, capacity, ns
 
 
-#: smallest row class of the compact lists
+#: smallest row class of the compact lists (the GEMM / chain epilogues pool classes 4, 8, 16, 32)
 COMPACT_SMIN = int(os.environ.get('DET6D_COMPACT_SMIN', '4'))
+COMPACT_SMALL_CLASSES = False
 
 
 def compact_groups(cnt, idx, n):
@@ -237,6 +238,36 @@ def chain_eligible(lda, layers, ns):
     if lda == 68 and c1 == 64 and c2 in (64, 96) and c3 == 128:      # wide register chain (SA2-sized groups)
         return CHAIN_WIDE
     return lda <= 8 and c1 <= 32 and c2 <= 32 and c3 <= 64
+
+
+#: compact-row groups through the register chain kernels (DET6D_COMPACT_NO_CHAIN=1: three det6d_linear launches)
+COMPACT_CHAIN = os.environ.get('DET6D_COMPACT_NO_CHAIN') is None
+
+
+def chain_compact_eligible(lda, layers):
+    if not COMPACT_CHAIN or len(layers) != 3 or not all(l[3] == 1 for l in layers):
+        return False
+    c = (layers[0][2], layers[1][2], layers[2][2])
+    if lda == 68 and c[0] == 64 and c[1] in (64, 96) and c[2] == 128:
+        return CHAIN_WIDE
+    return lda == 4 and c in ((16, 16, 32), (32, 32, 64))
+
+
+def mlp_chain3_compact(rows_pts, cr, ctr, layers, out, col0):
+    """mlp_chain3 over a CompactRows list"""
+    L.require_cuda(rows_pts, ctr, out)
+    (w1, s1, c1, _), (w2, s2, c2, _), (w3, s3, c3, _) = layers
+    ev = None
+    if LINEAR_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    L.call("det6d_mlp_chain3_compact", cr.capacity, L.ptr(cr.hdr), L.ptr(cr.crow_p), L.ptr(cr.crow_c), L.ptr(rows_pts),
+           rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1], L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
+           L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, L.ptr(out), out.shape[-1], col0, L.stream_ptr())
+    if ev is not None:
+        ev[1].record()
+        LINEAR_EVENTS.append((ev[0], ev[1], cr.hdr, 1, (rows_pts.shape[-1] * c1 + c1 * c2 + c2 * c3)))
+    return out
 
 
 def mlp_chain3(rows_pts, idx, ctr, cnt, layers, out, col0):

@@ -239,6 +239,10 @@ class _PointnetSAModuleFSBase(nn.Module):
         for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
             if COMPACT_ROWS and nsample in (4, 8, 16, 32):
                 cr = fused.compact_groups(idx_cnt, idx, n)
+                if fused.chain_compact_eligible(rows.shape[-1], layers):
+                    fused.mlp_chain3_compact(rows, cr, new_xyz, layers, pooled, col)
+                    col += layers[-1][2]
+                    continue
                 x = None
                 for li, (w, shift, cout, act) in enumerate(layers):
                     if li == len(layers) - 1:

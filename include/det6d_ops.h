@@ -324,7 +324,8 @@ typedef struct det6d_linear_args {
    * the DEVICE; `rows` is then the capacity (det6d_compact_rows_capacity) the launch is sized for. */
   const int *hdr;
   const int *crow_p;       /* mode COMPACT: point row (scene * n + neighbour) of every compact row; n = B * n */
-  const int *crow_c;       /* mode COMPACT / pool -1: centre (scene * m + j) of every compact row, -1 = padding */
+  const int *crow_c;       /* mode COMPACT / pool -1: centre (scene * m + j) of every compact row (bit 30: empty
+                              ball, pooled value 0), -1 = padding */
 } det6d_linear_args;
 int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
 
@@ -335,7 +336,8 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  *   cnt (B*m), idx (B,m,ns) as written by the ball queries;  ns, smin powers of two, smin <= ns <= 32;
  *   hdr (16) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
  *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment;
- *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row. */
+ *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row
+ *                 (crow_c: bit 30 set for an empty ball, -1 on alignment rows). */
 int det6d_compact_rows_capacity(int total_centres, int ns);
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, const int *cnt, const int *idx, int *hdr,
                          int *crow_p, int *crow_c, det6d_stream_t stream);
@@ -352,6 +354,13 @@ int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, co
                      const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1, const float *s1,
                      int c1, const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
                      const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream);
+
+/* det6d_mlp_chain3 over a compact row list (register kernels only: lda = 4 with (16,16,32) / (32,32,64), or the
+ * wide shapes); y[centre * ldy + col0 + c] for every centre of the list. */
+int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *crow_p, const int *crow_c, const float *a,
+                             int lda, const float *ctr, int ldctr, const float *w1, int ldw1, const float *s1, int c1,
+                             const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
+                             const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream);
 
 /* s-fps weights: w[i] = sigmoid(score[i]) ** gamma  (pointnet2_modules.py:415-419) */
 int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,

@@ -19,7 +19,10 @@ with torch.no_grad():
         acc = ms if acc is None else [min(a, b) for a, b in zip(acc, ms)]
 tot = 0
 for (e0, e1, r, k, n), t in zip(ev, acc):
+    cap = None
+    if torch.is_tensor(r):
+        h = r.cpu().numpy(); r, cap = int(h[0]), (int(h[7]), int(h[8]), int(h[9]))
     fl = 2.0 * r * k * n
     tot += t
-    print("rows %8d K %4d N %4d  %8.1f us  %6.1f TF  %6.2f GF" % (r, k, n, t * 1e3, fl / t / 1e9, fl / 1e9))
+    print("rows %8d K %4d N %4d  %8.1f us  %6.1f TF  %6.2f GF  %s" % (r, k, n, t * 1e3, fl / t / 1e9, fl / 1e9, cap or ''))
 print("total ms", tot)

@@ -1,0 +1,151 @@
+"""Compact (ragged) row lists of the grouped SA MLPs (csrc/compact.hip): the reference pads a ball holding
+cnt < nsample points with repetitions of its first cnt hits (ball_query_gpu.cu:75-90,114-129), so evaluating
+only the first 2^ceil(log2 cnt) slots of a centre must give the DENSE oracle's pooled features bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def padded_query(rng, b, n, m, ns, p_empty=0.05, p_full=0.1):
+    """(cnt, idx) with the reference's layout: ascending hits, then periodic repetition; zeros when empty"""
+    cnt = np.minimum(rng.geometric(0.25, (b, m)), ns).astype(np.int32)
+    u = rng.uniform(size=(b, m))
+    cnt[u < p_empty] = 0
+    cnt[u > 1 - p_full] = ns
+    idx = np.zeros((b, m, ns), np.int32)
+    for bi in range(b):
+        for j in range(m):
+            c = cnt[bi, j]
+            if c:
+                hits = np.sort(rng.choice(n, c, replace=False))
+                idx[bi, j] = hits[np.arange(ns) % c]
+    return cnt, idx
+
+
+@pytest.mark.parametrize("b,n,m,ns,smin", [(2, 500, 300, 16, 4), (3, 900, 1000, 32, 4), (1, 64, 7, 32, 1), (2, 300, 513, 16, 2),
+                                           (8, 2048, 4096, 32, 4), (2, 100, 50, 8, 4), (1, 40, 33, 4, 4)])
+def test_compact_groups_structure(b, n, m, ns, smin):
+    from de6d_amd.ops import fused
+    rng = np.random.default_rng(b * 1000 + m + ns)
+    cnt, idx = padded_query(rng, b, n, m, ns)
+    old = fused.COMPACT_SMIN
+    fused.COMPACT_SMIN = smin
+    try:
+        cr = fused.compact_groups(dev(cnt), dev(idx), n)
+    finally:
+        fused.COMPACT_SMIN = old
+    hdr, cp, cc = cr.hdr.cpu().numpy(), cr.crow_p.cpu().numpy(), cr.crow_c.cpu().numpy()
+    total = int(hdr[0])
+    assert total % 128 == 0 and total <= cr.capacity and cr.capacity % 1024 == 0
+    assert hdr[6] == total and hdr[7] == b * m and hdr[8] == np.minimum(cnt, ns).sum()
+    want_cls = np.maximum(smin, 2 ** np.ceil(np.log2(np.maximum(cnt, 1))).astype(np.int64)).reshape(-1)
+    want_cls = np.minimum(want_cls, ns)
+    seen = np.zeros(b * m, np.int64)
+    start = 0
+    for c in range(6):
+        s, end = 32 >> c, int(hdr[1 + c])
+        assert end % 128 == 0 and end >= start
+        members = np.nonzero(want_cls == s)[0]          # ascending centre order inside a region
+        if len(members) == 0:
+            assert end == start
+            continue
+        assert start + len(members) * s <= end < start + len(members) * s + 128
+        region_c = cc[start:start + len(members) * s].reshape(-1, s)
+        region_p = cp[start:start + len(members) * s].reshape(-1, s)
+        flat_cnt = cnt.reshape(-1)[members]
+        np.testing.assert_array_equal(region_c & 0x3fffffff, np.repeat(members[:, None], s, 1))
+        np.testing.assert_array_equal((region_c >> 30) & 1, np.repeat((flat_cnt == 0)[:, None], s, 1))
+        np.testing.assert_array_equal(region_p, idx.reshape(-1, ns)[members][:, :s] + (members // m * n)[:, None])
+        assert (cc[start + len(members) * s:end] == -1).all()
+        assert ((cp[start + len(members) * s:end] >= 0) & (cp[start + len(members) * s:end] < b * n)).all()
+        seen[members] += 1
+        start = end
+    assert (seen == 1).all()
+    assert hdr[9] == (want_cls).sum()
+
+
+def make_layers(rng, ld, c_in, widths):
+    dims = [ld] + list(widths)
+    layers_np, layers_dev = [], []
+    for i in range(3):
+        kin = dims[i] if i == 0 else (dims[i] + 3) // 4 * 4
+        wpad = (dims[i + 1] + 3) // 4 * 4
+        w = np.zeros((kin, wpad), np.float32)
+        k_used = dims[i] if i else 3 + c_in
+        w[:k_used, :dims[i + 1]] = rng.normal(size=(k_used, dims[i + 1])) / np.sqrt(dims[i])
+        s = rng.normal(size=(dims[i + 1],)).astype(np.float32)
+        layers_np.append((w, s))
+        layers_dev.append((dev(w), dev(s), dims[i + 1], 1))
+    return layers_np, layers_dev
+
+
+@pytest.mark.parametrize("c_in,widths,ns,chain", [(1, (16, 16, 32), 16, True), (1, (32, 32, 64), 32, True), (64, (64, 64, 128), 16, True),
+                                                   (64, (64, 96, 128), 32, True), (1, (32, 32, 64), 32, False),
+                                                   (128, (128, 128, 256), 16, False), (128, (128, 256, 256), 32, False),
+                                                   (5, (24, 40, 72), 8, False), (256, (256, 512, 1024), 32, False)])
+@pytest.mark.parametrize("smin", [4, 1])
+def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, smin):
+    """gather + 3 x (GEMM, shift, ReLU) + mask + max-pool over the compact rows (register chain kernels and the
+    three-GEMM route) == the oracle over ALL nsample rows"""
+    from de6d_amd.ops import fused
+    if smin < 4 and not fused.COMPACT_SMALL_CLASSES:
+        pytest.skip("row classes below 4 are not enabled in the GEMM epilogues")
+    b, n, m = 2, 700, 333
+    rng = np.random.default_rng(sum(widths) + ns)
+    ld = (3 + c_in + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3 + c_in] = rng.normal(size=(b, n, 3 + c_in))
+    ctr = rng.normal(size=(b, m, 3)).astype(np.float32)
+    cnt, idx = padded_query(rng, b, n, m, ns)
+    layers_np, layers_dev = make_layers(rng, ld, c_in, widths)
+    out = torch.full((b * m, widths[2] + 3), -7.0, device="cuda")
+    old = fused.COMPACT_SMIN
+    fused.COMPACT_SMIN = smin
+    try:
+        cr = fused.compact_groups(dev(cnt), dev(idx), n)
+    finally:
+        fused.COMPACT_SMIN = old
+    d_rows, d_ctr = dev(rows), dev(ctr)
+    if chain:
+        assert fused.chain_compact_eligible(ld, layers_dev)
+        fused.mlp_chain3_compact(d_rows, cr, d_ctr, layers_dev, out, 3)
+    else:
+        x = None
+        for li, (w, s, cout, act) in enumerate(layers_dev):
+            if li == 2:
+                tgt, kw = out, dict(ncols=cout, col0=3, cnt=dev(cnt), pool=-1)
+            else:
+                tgt, kw = torch.zeros((cr.capacity, w.shape[1]), device="cuda"), dict(ncols=cout)
+            if li == 0:
+                fused.linear(d_rows, w, s, act, tgt, ctr=d_ctr, compact=cr, gather=True, **kw)
+            else:
+                fused.linear(x, w, s, act, tgt, compact=cr, **kw)
+            x = tgt
+    h = oracle_ops.linear(rows, layers_np[0][0], layers_np[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(np.ascontiguousarray(np.pad(h, ((0, 0), (0, layers_np[1][0].shape[0] - h.shape[1])))), layers_np[1][0], layers_np[1][1], 1)
+    h = np.ascontiguousarray(np.pad(h[:, :widths[1]], ((0, 0), (0, layers_np[2][0].shape[0] - widths[1]))))
+    ref = np.full((b * m, widths[2] + 3), -7.0, np.float32)
+    oracle_ops.linear(h, layers_np[2][0][:, :widths[2]], layers_np[2][1], 1, cnt=cnt, pool=ns, out=ref, col0=3)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}])
+def test_model_parity_on_the_other_row_paths(env):
+    """the whole-model bit-exact tests run on compact rows with the chain kernels by default; rerun a subset on the
+    reference's dense row space and on the three-GEMM compact route (switches are read at import: child process)"""
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_model_gpu.py'), '-q', '-x', '-m', 'gpu',
+                          '-k', 'tiny or sloped or three_class'], env=dict(os.environ, **env), cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'passed' in out.stdout
