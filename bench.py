@@ -33,7 +33,7 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from de6d_amd.runtime import load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
+from de6d_amd.runtime import Det6DGroup, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd.ops import fused  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
@@ -199,7 +199,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=22, help='passes in flight; keep it below GPU_MAX_HW_QUEUES - 1 (24 queues: 18 -> 4454, 20 -> 4500, 22 -> 4549, 23 -> 4434 scenes/s; 16 queues: 15 -> 4372)')
+    ap.add_argument('--streams', type=int, default=16, help='passes in flight; keep it below GPU_MAX_HW_QUEUES - 1 (24 queues: 18 -> 4454, 20 -> 4500, 22 -> 4549, 23 -> 4434 scenes/s; 16 queues: 15 -> 4372)')
+    ap.add_argument('--prefetch', type=int, default=4, help='groups whose sampler stage is issued ahead of the GEMM stage')
+    ap.add_argument('--sampler-streams', type=int, default=6)
+    ap.add_argument('--group', type=int, default=4, help='passes whose first (input-only) sampler runs as one high-priority launch; 1 = every pass is a single captured graph')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -247,19 +250,48 @@ def main():
             return dets
     else:
         # one captured hipGraph per stream, all reading the same resident input batch
-        runners = [GraphedDet6D(model, b, n, points=None if args.h2d else points) for _ in range(depth)]
         host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
+        k = max(1, min(args.group, depth))
+        if k >= 1 and args.group > 0:
+            # two-stage software pipeline: stage 1 = pack + first sampler of a group of k passes, one launch on a
+            # sampler stream, issued `prefetch` groups ahead; stage 2 = the rest of each pass (captured graph
+            # segments) on `depth` main streams.  Every pass still processes its own batch of b scenes.
+            n_main = depth
+            mains = [torch.cuda.Stream() for _ in range(n_main)]
+            samp = [torch.cuda.Stream(priority=int(os.environ.get('DET6D_GROUP_PRIO', '0'))) for _ in range(args.sampler_streams)]
+            n_groups = max(1, n_main // k) + args.prefetch
+            runners = [Det6DGroup(model, b, n, k, samp[g % len(samp)], points=None if args.h2d else points,
+                                  main_streams=[mains[(g * k + j) % n_main] for j in range(k)]) for g in range(n_groups)]
 
-        def run(steps):
-            inflight, dets = [], 0
-            for i in range(steps):
-                r = runners[i % depth]
-                if len(inflight) >= depth:
-                    dets += sum(len(p['pred_scores']) for p in inflight.pop(0).finalize())
-                inflight.append(r.launch(host_batch))
-            for r in inflight:
-                dets += sum(len(p['pred_scores']) for p in r.finalize())
-            return dets
+            def run(steps):
+                counts, left = [], steps
+                while left > 0:
+                    counts.append(min(k, left)); left -= counts[-1]
+                dets, inflight = 0, []
+                for g in range(min(args.prefetch, len(counts))):
+                    runners[g % n_groups].launch_front(host_batch, counts[g])
+                for g in range(len(counts)):
+                    if len(inflight) >= n_groups - args.prefetch:
+                        dets += sum(len(p['pred_scores']) for r in inflight.pop(0) for p in r.finalize())
+                    if g + args.prefetch < len(counts):
+                        runners[(g + args.prefetch) % n_groups].launch_front(host_batch, counts[g + args.prefetch])
+                    inflight.append(runners[g % n_groups].launch_rest())
+                for grp in inflight:
+                    dets += sum(len(p['pred_scores']) for r in grp for p in r.finalize())
+                return dets
+        else:
+            runners = [GraphedDet6D(model, b, n, points=None if args.h2d else points) for _ in range(depth)]
+
+            def run(steps):
+                inflight, dets = [], 0
+                for i in range(steps):
+                    r = runners[i % depth]
+                    if len(inflight) >= depth:
+                        dets += sum(len(p['pred_scores']) for p in inflight.pop(0).finalize())
+                    inflight.append(r.launch(host_batch))
+                for r in inflight:
+                    dets += sum(len(p['pred_scores']) for p in r.finalize())
+                return dets
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -292,7 +324,7 @@ def main():
                                    "(3-layer FSMSG SA + 6-DoF vote head + rotated NMS), random-init seeded "
                                    "weights; BASELINE.json configs[1]" % (b, n),
                        "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n,
-                       "streams": depth, "hipgraph": not args.no_graph, "input": "pinned host, H2D per step" if args.h2d else "resident in HBM", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
+                       "streams": depth, "sampler_group": max(1, min(args.group, depth)), "hipgraph": not args.no_graph, "input": "pinned host, H2D per step" if args.h2d else "resident in HBM", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, points, b, flops)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/det6d_math.h"
 #include "../../include/det6d_ops.h"
@@ -93,6 +94,32 @@ __device__ __forceinline__ float d6_relu(float v) {
   float r;
   asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
   return r;
+}
+
+// The samplers are latency chains of a few hundred dependent vector-ALU instructions per round on ONE workgroup
+// per scene, co-resident with GEMM waves whose fp32 MFMAs occupy the same vector ALU for 64 cycles each: at the
+// default priority every sampler instruction queues behind an MFMA.  Raised wave priority lets the chain's
+// instructions issue first (the GEMM waves lose a few issue slots per round, the sampler leaves the CU sooner).
+__device__ __forceinline__ void d6_sampler_priority() {
+#ifndef DET6D_NO_SAMPLER_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
+// Dynamic LDS a sampler launch asks for ON TOP of its static use so that no workgroup that needs more than a few
+// KB of LDS (every GEMM-family kernel) becomes co-resident with it: beside fp32-MFMA waves the sampler's dependent
+// vector-ALU chain runs 5-6x slower (each instruction queues behind a 64-cycle MFMA; scripts/gpu_fps_interf.py:
+// 3.6 -> 16-20 ms for the SA1 sampler), which keeps half the chip's CUs hosting samplers.  DET6D_FPS_LDS_HOG=0
+// turns the reservation off.
+template <typename KernelT>
+static inline unsigned det6d_sampler_lds_hog(KernelT kernel, unsigned static_bytes) {
+  static const int keep_kb = getenv("DET6D_FPS_LDS_HOG") ? atoi(getenv("DET6D_FPS_LDS_HOG")) : 8;   // LDS left to others (KB); 0 = no reservation
+  if (keep_kb <= 0) return 0u;
+  const unsigned total = 160u * 1024u, keep = (unsigned)keep_kb * 1024u;
+  if (static_bytes + keep >= total) return 0u;
+  const unsigned dyn = total - keep - static_bytes;
+  hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  return dyn;
 }
 
 __device__ __forceinline__ float d6_readlane_f(float v, int lane) {

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
   const int lane = h & 63;
   const int wave = h >> 6;
   const int log2vpt = log2s - LOG2T;            // virtual threads per hardware thread
+  d6_sampler_priority();
 
   xyz += (size_t)blockIdx.x * vw.xyz_bstride;
   if (temp) temp += (size_t)blockIdx.x * vw.temp_bstride;
@@ -421,7 +422,8 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
   do {                                                                                         \
     int lp = 0;                                                                                \
     while ((1 << lp) < ppt) ++lp;                                                              \
-    hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), 0, stream, n, m, log2s, \
+    static const unsigned hog = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W>, 1024);        \
+    hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
                        lp, xyz, weights, temp, idx, vw);                                       \
     return det6d_check_launch("det6d_fps");                                                    \
   } while (0)

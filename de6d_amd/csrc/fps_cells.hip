@@ -290,6 +290,9 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 // G groups per wave: group g of a wave = slots g*SG .. (g+1)*SG-1 of its 64 lanes = 64*SG consecutive sorted
 // points with their own bounding box and cached arg-max (G = 1: one box per wave).
+// timing experiments only (DET6D_FPS_DBG=7): wall clock (100 MHz) at the first and after the last round of every scene
+__device__ unsigned long long d6_fps_clock[2 * 64];
+
 template <int NW, int SLOTS, int G>
 __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log2s, long long xyz_bstride,
                                                            long long idx_bstride, int idx_add, int dbg,
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   __shared__ int slot_k[2][NW];
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
+  d6_sampler_priority();
   xyz += (size_t)blockIdx.x * xyz_bstride;
   perm += (size_t)blockIdx.x * n;
   idxs += (size_t)blockIdx.x * idx_bstride;
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
 
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
   if (h == 0) idxs[0] = idx_add;
+  if (dbg == 7 && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x] = wall_clock64();
   // cached arg-max of every group of this wave (uniform)
   float cg_val[G], cg_x[G], cg_y[G], cg_z[G];
   int cg_k[G];
@@ -414,9 +419,15 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
     cz = d6_readlane_f(z2, ww);
     if (h == 0) idxs[r] = old + idx_add;
   }
+  if (dbg == 7 && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 }  // namespace
+
+// timing experiments only: copies the 2 x 64 clock samples of the last DET6D_FPS_DBG=7 sampler launch to the host
+extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsigned long long *out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(d6_fps_clock), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
 
 // Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
@@ -442,7 +453,8 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
                          idx_add, dbg, xyz, perm, idx);
     } else if (skip != 162) {
       hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+      static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
+      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,
                          idx_add, dbg, xyz, perm, idx);
     } else {
       hipLaunchKernelGGL(skip_group_order_kernel<8>, dim3(4, b), dim3(512), 0, stream, n, log2s, perm);

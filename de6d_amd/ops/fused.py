@@ -17,18 +17,32 @@ def pack_points(points, ld):
     """(B*N, 1+3+C) [b,x,y,z,f..] -> rows (B*N, ld) [x,y,z,f..,0..]  (pointnet2_backbone.py:193-224)"""
     L.require_cuda(points)
     total, width = points.shape
-    rows = torch.empty((total, ld), dtype=torch.float32, device=points.device)
-    xyz = torch.empty((total, 3), dtype=torch.float32, device=points.device)
+    ctl = SAMPLER_SEGMENTS
+    if ctl is not None and ctl.pack_out is not None:   # a Det6DGroup owns the packed input of its passes
+        rows, xyz = ctl.pack_out[0].view(total, ld), ctl.pack_out[1].view(total, 3)
+    else:
+        rows = torch.empty((total, ld), dtype=torch.float32, device=points.device)
+        xyz = torch.empty((total, 3), dtype=torch.float32, device=points.device)
     L.call("det6d_pack_points", total, width - 4, L.ptr(points), ld, L.ptr(rows), L.ptr(xyz), L.stream_ptr())
     return rows, xyz
 
 
-def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
+#: capture controller of runtime.GraphedDet6D: while it is recording, sampler calls are not launched but handed
+#: to it (they replay as eager launches on a high-priority stream between the captured graph segments)
+SAMPLER_SEGMENTS = None
+
+
+def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None):
     """one sampler of an SA layer: range slice, sigmoid**gamma weights, 1e10 init, +lo offset and the
     write into the concatenated index buffer all happen inside the kernel"""
     L.require_cuda(xyz, scores, idx_out)
     b, n_total, _ = xyz.shape
-    temp = torch.empty((b, hi - lo), dtype=torch.float32, device=xyz.device)
+    ctl = SAMPLER_SEGMENTS
+    if ctl is not None and ctl.recording:
+        ctl.add_sampler(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset)
+        return
+    if temp is None:
+        temp = torch.empty((b, hi - lo), dtype=torch.float32, device=xyz.device)
     L.call("det6d_fps_fused", b, n_total, lo, hi, m, L.ptr(xyz), L.ptr(scores), float(gamma), L.ptr(temp),
            L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
 

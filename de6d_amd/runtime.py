@@ -83,6 +83,82 @@ def mlp_flops_per_scene(model, n_points):
     return total
 
 
+#: Farthest point sampling is ONE 1024-thread workgroup per scene running a 4095-round latency chain.  Inside a
+#: stream of GEMM workgroups at equal queue priority such a workgroup waits 10-20 ms for a CU with enough free
+#: registers / wave slots (scripts/gpu_cumask.py: 3.6 ms alone, 19 ms beside four GEMM streams, 5.5 ms from a
+#: high-priority queue), which kept 22 passes in flight and half the chip's CUs hosting samplers.  HIP gives
+#: high-priority streams only FOUR hardware queues (scripts/gpu_prio_queues.py), so the first sampler — the one
+#: that depends on nothing but the input cloud — is cut out of the captured passes and launched ONCE for a group
+#: of passes on a high-priority stream (Det6DGroup); everything else replays as graph segments at normal priority.
+SAMPLER_GROUP = int(os.environ.get('DET6D_SAMPLER_GROUP', '4'))
+
+
+class _SegmentCapture(object):
+    """capture controller: graph segments on `main`; the first sampler is left to the group (front buffers given),
+    later samplers stay inline unless `eager_rest` (then they replay as eager launches between segments)"""
+
+    def __init__(self, main, pool, front=None, eager_rest=False):
+        self.main, self.pool = main, pool
+        self.front, self.eager_rest = front, eager_rest
+        self.segments = []          # [(graph, [sampler call, ...])]
+        self.recording = False
+        self.pack_out = None if front is None else (front[0], front[1])
+        self._graph = self._ctx = None
+        self._calls = None
+        self._n_sample = 0
+        self._mode = None
+
+    def begin(self):
+        self._graph = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.stream(self.main)
+        self._ctx.__enter__()
+        self._graph.capture_begin(pool=self.pool)
+
+    def end(self):
+        self._graph.capture_end()
+        self._ctx.__exit__(None, None, None)
+        self.segments.append((self._graph, []))
+        self._graph = self._ctx = None
+
+    def sample_index_buffer(self, b, m):
+        """index buffer of the next _sample call: the group's for the first sampler, None = allocate as usual"""
+        if self.front is not None and self._n_sample == 0:
+            assert tuple(self.front[2].shape) == (b, m)
+            return self.front[2]
+        return None
+
+    def enter_samplers(self):
+        self._n_sample += 1
+        if self.front is not None and self._n_sample == 1:
+            self._mode = 'front'
+        elif self.eager_rest:
+            self._mode = 'eager'
+        else:
+            self._mode = None
+            return
+        self._graph.capture_end()
+        self._ctx.__exit__(None, None, None)
+        self._calls = []
+        self.recording = True
+
+    def add_sampler(self, xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
+        if self._mode == 'front':   # launched by the group for all its passes at once: must be the plain input-only D-FPS
+            if not (scores is None and lo == 0 and hi == xyz.shape[1] and idx_offset == 0 and m == idx_out.shape[1]
+                    and xyz.data_ptr() == self.front[1].data_ptr() and idx_out.data_ptr() == self.front[2].data_ptr()):
+                raise NotImplementedError("grouped first sampler: expected one d-fps over the whole input cloud")
+            return
+        temp = torch.empty((xyz.shape[0], hi - lo), dtype=torch.float32, device=xyz.device)   # owned by the call
+        self._calls.append((xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp))
+
+    def exit_samplers(self):
+        if self._mode is None:
+            return
+        self.recording = False
+        self.segments.append((self._graph, self._calls))
+        self._calls = None
+        self.begin()
+
+
 class GraphedDet6D(object):
     """One Det6D pass (backbone -> head -> fused post-processing) captured into a hipGraph on its
     own HIP stream: ~130 kernel launches replay with a single host call, so several batches can be
@@ -91,11 +167,15 @@ class GraphedDet6D(object):
     The captured graph reads `self.points` (static input, (B*N, 1+3+C)); pass a tensor to launch()
     to have it copied in first, or write into `self.points` yourself."""
 
-    def __init__(self, model, batch_size, n_points, point_width=5, points=None, warmup=2):
+    def __init__(self, model, batch_size, n_points, point_width=5, points=None, warmup=2, front=None, hi_stream=None,
+                 stream=None):
+        """front = (rows, xyz, idx) slices of a Det6DGroup: the pass packs its points into them and takes the first
+        sampler's indices from idx (the group launches that sampler for all its passes)"""
         from .ops import fused
         self.model = model
         self.batch_size = batch_size
-        self.stream = torch.cuda.Stream()
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.hi_stream = hi_stream
         self.points = points if points is not None else torch.zeros(
             (batch_size * n_points, point_width), dtype=torch.float32, device='cuda')
         pp = model.model_cfg.POST_PROCESSING
@@ -117,16 +197,65 @@ class GraphedDet6D(object):
             for _ in range(warmup):
                 body()
         self.stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
-            self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
+        self.segments = None
+        if front is not None:
+            torch.cuda.synchronize()
+            ctl = _SegmentCapture(self.stream, torch.cuda.graph_pool_handle(), front=front)
+            fused.SAMPLER_SEGMENTS = ctl
+            try:
+                with torch.no_grad():
+                    ctl.begin()
+                    self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
+                    ctl.end()
+            finally:
+                fused.SAMPLER_SEGMENTS = None
+            self.segments = ctl.segments
+            self._ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self.segments]
+            self._fps = fused.fps_fused
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
+                self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
         self.count_host = torch.empty(self.count.shape, dtype=self.count.dtype, pin_memory=True)
         self.done = torch.cuda.Event()
+
+    def launch_front(self, points=None):
+        """segment 0 (everything before the first sampler) on the CURRENT stream (the group's sampler stream), once
+        the pass's previous launch has finished with the buffers"""
+        torch.cuda.current_stream().wait_event(self.done)
+        if points is not None and points.data_ptr() != self.points.data_ptr():
+            self.points.copy_(points, non_blocking=True)
+        self.segments[0][0].replay()
+
+    def launch_rest(self, sampled):
+        """the remaining segments once the group's sampler (event `sampled`) has run"""
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(sampled)
+            self._replay(first=1)
+            self.count_host.copy_(self.count, non_blocking=True)
+            self.done.record()
+        return self
+
+    def _replay(self, first=0):
+        """graph segments on the pass's stream, eager samplers between them on the high-priority stream"""
+        main, hi = self.stream, self.hi_stream
+        for (graph, calls), (e_main, e_hi) in list(zip(self.segments, self._ev))[first:]:
+            graph.replay()
+            if calls:
+                e_main.record(main)
+                hi.wait_event(e_main)
+                with torch.cuda.stream(hi):
+                    for xyz, lo, hi_, m, scores, gamma, idx_out, idx_offset, temp in calls:
+                        self._fps(xyz, lo, hi_, m, scores, gamma, idx_out, idx_offset, temp=temp)
+                e_hi.record(hi)
+                main.wait_event(e_hi)
 
     def launch(self, points=None):
         with torch.cuda.stream(self.stream):
             if points is not None and points.data_ptr() != self.points.data_ptr():
                 self.points.copy_(points, non_blocking=True)
+            if self.segments is not None:
+                raise RuntimeError("this pass belongs to a Det6DGroup: launch the group")
             self.graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
             self.done.record()
@@ -137,3 +266,56 @@ class GraphedDet6D(object):
         self.done.synchronize()
         return [{'pred_boxes': self.boxes[i, :k], 'pred_scores': self.scores[i, :k],
                  'pred_labels': self.labels[i, :k].long()} for i, k in enumerate(self.count_host.tolist())]
+
+
+class Det6DGroup(object):
+    """K captured passes whose FIRST sampler (D-FPS over the input cloud: depends on nothing else) runs as one
+    launch over all K x B scenes on a stream of its own; see SAMPLER_GROUP above.  Two stages:
+      launch_front(): pack + first sampler of the K passes on `sampler_stream` (waits until the passes' previous
+                      launch is done with the buffers);
+      launch_rest():  the remaining graph segments of every pass on its main stream, after the sampler.
+    Issue launch_front() of later groups BEFORE launch_rest() of earlier ones and the samplers (one 1024-thread
+    workgroup per scene, a 3.5 ms latency chain that waits 10-20 ms for a free CU beside GEMM traffic) run ahead of
+    the GEMM stage instead of blocking its streams.  launch() = both stages back to back."""
+
+    def __init__(self, model, batch_size, n_points, k, sampler_stream, point_width=5, points=None, main_streams=None):
+        from .ops import fused
+        from .pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import rows_ld
+        sa1 = model.backbone_3d.SA_modules[0]
+        m1 = sum(sa1.npoint_list)
+        ld = rows_ld(point_width - 4)
+        dev = 'cuda'
+        self.k, self.batch_size, self.n_points, self.m1 = k, batch_size, n_points, m1
+        self.hi = sampler_stream
+        self.rows_all = torch.empty((k * batch_size, n_points, ld), dtype=torch.float32, device=dev)
+        self.xyz_all = torch.empty((k * batch_size, n_points, 3), dtype=torch.float32, device=dev)
+        self.idx_all = torch.empty((k * batch_size, m1), dtype=torch.int32, device=dev)
+        self.temp_all = torch.empty((k * batch_size, n_points), dtype=torch.float32, device=dev)
+        self.runners = []
+        for j in range(k):
+            sl = slice(j * batch_size, (j + 1) * batch_size)
+            self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=points,
+                                             front=(self.rows_all[sl], self.xyz_all[sl], self.idx_all[sl]),
+                                             stream=None if main_streams is None else main_streams[j % len(main_streams)]))
+        self._fps = fused.fps_fused
+        self._sampled = torch.cuda.Event()
+        self._count = k
+
+    def launch_front(self, points=None, count=None):
+        self._count = self.k if count is None else count
+        nb = self._count * self.batch_size
+        with torch.cuda.stream(self.hi):
+            for r in self.runners[:self._count]:
+                r.launch_front(points)
+            self._fps(self.xyz_all[:nb], 0, self.n_points, self.m1, None, 1.0, self.idx_all[:nb], 0, temp=self.temp_all[:nb])
+            self._sampled.record(self.hi)
+        return self
+
+    def launch_rest(self):
+        active = self.runners[:self._count]
+        for r in active:
+            r.launch_rest(self._sampled)
+        return active
+
+    def launch(self, points=None, count=None):
+        return self.launch_front(points, count).launch_rest()

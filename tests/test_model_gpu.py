@@ -152,6 +152,33 @@ def test_graph_replay_equals_eager(oracle_ops):
         assert torch.equal(g['pred_boxes'], e['pred_boxes'])
 
 
+def test_pass_group_equals_eager(oracle_ops):
+    """Det6DGroup (bench.py's runner: graph segments per pass, the first sampler of the group's passes as one
+    high-priority launch) returns exactly the eager detections of every pass, with different inputs per pass and
+    with partially filled groups"""
+    from de6d_amd.runtime import load_config, build_model, Det6DGroup
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=9, device='cuda')
+    b, n, k = 2, 2048, 3
+    group = Det6DGroup(model, b, n, k, torch.cuda.Stream(priority=-1))
+    batches = [torch.from_numpy(flat_points(make_batch(300 + 7 * j, b, n))).cuda() for j in range(k)]
+    eager = []
+    with torch.no_grad():
+        for pts in batches:
+            eager.append(model({'batch_size': b, 'points': pts})[0])
+    for rep in range(3):
+        count = k if rep != 1 else 2
+        for r, pts in zip(group.runners[:count], batches):
+            r.points.copy_(pts)
+        torch.cuda.synchronize()
+        passes = group.launch(count=count)
+        assert len(passes) == count
+        for r, want in zip(passes, eager):
+            for g, e in zip(r.finalize(), want):
+                assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+                assert torch.equal(g['pred_labels'], e['pred_labels'])
+
+
 def test_generic_post_processing_route_matches_fused(oracle_ops):
     """class_agnostic_nms + nms_gpu through the op-level API (the route taken for non-fusable configs)
     selects the same boxes as the fused post-processing kernels and the oracle"""
