@@ -164,8 +164,15 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
 
 
 def linear_roofline(model, points, batch, flops_per_scene):
-    """average achieved TFLOP/s of the dominant kernel family (linear_kernel: the SA / head MLP
-    GEMMs) measured live with HIP events on the launch stream over one step"""
+    """average achieved TFLOP/s of the dominant kernel family (linear_kernel + the register chain kernels: the
+    SA / head MLP GEMMs) measured live with HIP events on the launch stream over one step.
+
+    The grouped MLPs run on compact row lists (csrc/compact.hip): rows that only repeat another row of the same
+    centre (the reference's padding of partly filled balls) are not evaluated.  Three flop counts are reported:
+      algorithmic = rows that carry information (sum of min(cnt, nsample) per group; every row of the plain layers),
+      issued      = rows the kernels actually multiply (class padding to 4 / 8 / 16 / 32 and 128-row alignment on top),
+      dense       = the reference's (centres x nsample) row space, SURVEY.md 8d's 22.583 GFLOP per scene.
+    `achieved` prices the ALGORITHMIC flops: padding the kernels add for their own convenience earns nothing."""
     fused.LINEAR_EVENTS = []
     with torch.no_grad():
         model({'batch_size': batch, 'points': points})
@@ -173,9 +180,19 @@ def linear_roofline(model, points, batch, flops_per_scene):
     ev = fused.LINEAR_EVENTS
     fused.LINEAR_EVENTS = None
     total_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
-    issued = sum(2.0 * r * k * n for _, _, r, k, n in ev)
-    alg = flops_per_scene * batch
-    achieved = alg / (total_ms * 1e-3) / 1e12
+    issued = useful = 0.0
+    fill = []
+    for _, _, r, k, n in ev:
+        if torch.is_tensor(r):          # compact list header: [0] issued rows, [7] centres, [8] information rows
+            h = r.cpu().tolist()
+            issued += 2.0 * h[0] * k * n
+            useful += 2.0 * h[8] * k * n
+            fill.append((h[7], h[8], h[0]))
+        else:
+            issued += 2.0 * r * k * n
+            useful += 2.0 * r * k * n
+    dense = flops_per_scene * batch
+    achieved = useful / (total_ms * 1e-3) / 1e12
     traffic = None
     pmc = sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')))
     if pmc:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
@@ -183,12 +200,17 @@ def linear_roofline(model, points, batch, flops_per_scene):
             traffic = round(json.load(open(pmc[-1]))['_derived']['linear_kernel']['hbm_bytes_per_launch'])
         except Exception:
             traffic = None
+    groups = sorted(set(fill))
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": os.path.basename(pmc[-1]) if pmc and traffic else None,
-            "kernel": "linear_kernel<...> + mlp_chain_kernel (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
+            "kernel": "linear_kernel<...> + mlp_chain_*_kernel (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
             "launches_per_step": len(ev), "avg_launch_us": round(total_ms * 1e3 / max(len(ev), 1), 2),
-            "algorithmic_gflop_per_step": round(alg / 1e9, 2), "issued_gflop_per_step": round(issued / 1e9, 2),
+            "algorithmic_gflop_per_step": round(useful / 1e9, 2), "issued_gflop_per_step": round(issued / 1e9, 2),
+            "dense_gflop_per_step": round(dense / 1e9, 2),
+            "issued_tflops": round(issued / (total_ms * 1e-3) / 1e12, 2),
+            "dense_equivalent_tflops": round(dense / (total_ms * 1e-3) / 1e12, 2),
+            "compact_rows_centres_information_issued": groups,
             "kernel_ms_per_step": round(total_ms, 3)}
 
 

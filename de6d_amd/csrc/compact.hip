@@ -24,19 +24,37 @@ namespace {
 
 constexpr int kClasses = 6;
 
-__device__ __forceinline__ int class_of(int cnt, int ns, int smin) {   // class index c, s = 32 >> c
-  int s = smin;
-  while (s < cnt && s < ns) s <<= 1;
-  return 5 - (31 - __builtin_clz(s));   // s = 32 -> 0 ... s = 1 -> 5
+// classes (bit c <-> s = 32 >> c) the rows of a centre with `cnt` hits are placed in.
+//   split = 0: one part, the next power of two >= max(cnt, smin);
+//   split = 1: ceil(cnt / smin) * smin rows, cut along their binary digits into parts of descending size (20 rows =
+//              16 + 4: slots 0..15 form a class-16 group, slots 16..19 a class-4 group); the pooled value of the
+//              centre is the maximum over its parts, combined by an integer atomic max on the (non-negative, post-ReLU)
+//              outputs (bit 29 of crow_c marks such rows; the pooled buffer is zeroed first).
+__device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split, int *rows_out) {
+  const int k = cnt < 1 ? 1 : (cnt > ns ? ns : cnt);
+  int rows;
+  if (split) {
+    rows = (k + smin - 1) / smin * smin;
+  } else {
+    rows = smin;
+    while (rows < k) rows <<= 1;
+  }
+  *rows_out = rows;
+  int mask = 0;
+#pragma unroll
+  for (int c = 0; c < kClasses; ++c)
+    if (rows & (32 >> c)) mask |= 1 << c;
+  return mask;
 }
 
-__global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, int m, int ns, int smin, const int *__restrict__ cnt,
-                                                             const int *__restrict__ idx, int *__restrict__ hdr,
-                                                             int *__restrict__ crow_p, int *__restrict__ crow_c) {
+__global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, int m, int ns, int smin, int split,
+                                                             const int *__restrict__ cnt, const int *__restrict__ idx,
+                                                             int *__restrict__ hdr, int *__restrict__ crow_p,
+                                                             int *__restrict__ crow_c) {
   __shared__ int h_all[kClasses], h_before[kClasses], h_real;
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
-  __shared__ int r0_s[256], cls_s[256];
+  __shared__ int r0_s[256][kClasses], rows_s[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = (((total + gridDim.x - 1) / gridDim.x) + 255) & ~255;
   const int c_lo = blockIdx.x * chunk;
@@ -50,12 +68,13 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
     for (int c = 0; c < kClasses; ++c) la[c] = lb[c] = 0;
     for (int i = tid; i < total; i += 256) {
       const int k = cnt[i];
-      const int c = class_of(k, ns, smin);
+      int rows;
+      const int mask = parts_of(k, ns, smin, split, &rows);
       real += k < ns ? k : ns;
 #pragma unroll
       for (int cc = 0; cc < kClasses; ++cc) {
-        la[cc] += c == cc;
-        lb[cc] += (c == cc) & (i < c_lo);
+        la[cc] += (mask >> cc) & 1;
+        lb[cc] += ((mask >> cc) & 1) & (i < c_lo);
       }
     }
 #pragma unroll
@@ -90,38 +109,48 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
       for (int r = e + tid; r < start[c + 1]; r += 256) { crow_p[r] = 0; crow_c[r] = -1; }
     }
   }
-  // ---- ordered placement of this chunk, 256 centres at a time: first row r0 and class of every centre into
-  //      LDS (ballot ranks), then one thread per (centre, slot) so that idx is read and the rows are written
-  //      with consecutive lanes on consecutive words ----
+  // ---- ordered placement of this chunk, 256 centres at a time: first row of every part of every centre into
+  //      LDS (ballot ranks per class), then one thread per (centre, slot) so that idx is read and the rows are
+  //      written with consecutive lanes on consecutive words ----
   for (int i0 = c_lo; i0 < c_hi; i0 += 256) {
     const int i = i0 + tid;
     const bool ok = i < c_hi;
-    const int c = ok ? class_of(cnt[i], ns, smin) : -1;
-    int rank = 0;
+    int rows = 0;
+    const int mask = ok ? parts_of(cnt[i], ns, smin, split, &rows) : 0;
+    int rank[kClasses];
 #pragma unroll
     for (int cc = 0; cc < kClasses; ++cc) {
-      const unsigned long long mk = __ballot(c == cc);
-      if (c == cc) rank = __popcll(mk & ((1ull << lane) - 1ull));
+      const unsigned long long mk = __ballot((mask >> cc) & 1);
+      rank[cc] = __popcll(mk & ((1ull << lane) - 1ull));
       if (lane == 0) wave_cnt[wave][cc] = __popcll(mk);
     }
     __syncthreads();
-    if (ok) {
+    rows_s[tid] = rows;
+#pragma unroll
+    for (int cc = 0; cc < kClasses; ++cc) {
       int before = 0;
-      for (int w = 0; w < wave; ++w) before += wave_cnt[w][c];
-      r0_s[tid] = base[c] + (before + rank) * (32 >> c);
-      cls_s[tid] = 32 >> c;
-    } else {
-      cls_s[tid] = 0;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w][cc];
+      r0_s[tid][cc] = base[cc] + (before + rank[cc]) * (32 >> cc);
     }
     __syncthreads();
     if (tid < kClasses) base[tid] += (wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]) * (32 >> tid);
     const int lg = 31 - __builtin_clz(ns);
     for (int e = tid; e < 256 * ns; e += 256) {
       const int ci = e >> lg, t = e & (ns - 1);
-      if (t < cls_s[ci]) {
+      const int rw = rows_s[ci];
+      if (t < rw) {
         const int cg = i0 + ci;
-        crow_p[r0_s[ci] + t] = (cg / m) * n + idx[(size_t)cg * ns + t];
-        crow_c[r0_s[ci] + t] = cnt[cg] > 0 ? cg : (cg | 0x40000000);
+        int row = 0;
+#pragma unroll
+        for (int cc = 0; cc < kClasses; ++cc) {   // the part that holds slot t: parts in descending size
+          const int sz = 32 >> cc, off = rw & ~(2 * sz - 1);
+          if ((rw & sz) && t >= off && t < off + sz) row = r0_s[ci][cc] + (t - off);
+        }
+        int tag = cg;
+        if (cnt[cg] <= 0) tag |= 0x40000000;          // empty ball: pooled value 0
+        if (rw & (rw - 1)) tag |= 0x20000000;          // several parts: combine with an atomic max
+        crow_p[row] = (cg / m) * n + idx[(size_t)cg * ns + t];
+        crow_c[row] = tag;
       }
     }
     __syncthreads();
@@ -134,8 +163,8 @@ DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
   return (total_centres * ns + kClasses * 128 + 1023) & ~1023;   // a multiple of 8 row tiles: keeps the XCD-aware tile order
 }
 
-DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, const int *cnt, const int *idx, int *hdr,
-                                   int *crow_p, int *crow_c, det6d_stream_t stream) {
+DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx,
+                                   int *hdr, int *crow_p, int *crow_c, det6d_stream_t stream) {
   if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
   if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
   if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
@@ -143,7 +172,7 @@ DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, const 
   int blocks = det6d_divup(total, 256);   // every workgroup reads all counts once (prefix of its chunk): keep them few
   if (blocks > 128) blocks = 128;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, cnt, idx,
-                     hdr, crow_p, crow_c);
+  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split ? 1 : 0,
+                     cnt, idx, hdr, crow_p, crow_c);
   return det6d_check_launch("det6d_compact_groups");
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         arow[i] = g.a + (size_t)g.crow_p[r] * g.lda;
         const int cj = g.crow_c[r];
         if (akq == 0 && cj >= 0) {
-          const float *c = g.ctr + (size_t)(cj & 0x3fffffff) * g.ldctr;
+          const float *c = g.ctr + (size_t)(cj & 0x1fffffff) * g.ldctr;
           csub[i][0] = c[0]; csub[i][1] = c[1]; csub[i][2] = c[2];
         }
       } else {
@@ -455,8 +455,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const int cj = pre_ctr[i][qq];
-          if (cok && cj >= 0)
-            g.y[(size_t)cj * g.ldy + g.col0 + col] = pre_cnt[i][qq] > 0 ? relu_act(v[qq] + sh, g.act) : 0.f;
+          if (cok && cj >= 0) {
+            const float val = pre_cnt[i][qq] > 0 ? relu_act(v[qq] + sh, g.act) : 0.f;
+            float *dst = g.y + (size_t)(cj & 0x1fffffff) * g.ldy + g.col0 + col;
+            // bit 29: the centre's rows are cut into several parts (compact.hip, split lists): maximum over the parts
+            // by an integer atomic max on the non-negative post-ReLU values (the buffer was zeroed)
+            if (cj & 0x20000000) __hip_atomic_fetch_max(reinterpret_cast<int *>(dst), __builtin_bit_cast(int, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = val;
+          }
         }
       }
     }
@@ -537,8 +543,8 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   } else if (a->mode != DET6D_A_ROWS) {
     return DET6D_EINVAL;
   }
-  if (a->pool < 0) {   // class pooling over compact rows
-    if (!a->hdr || !a->crow_c) return DET6D_EINVAL;
+  if (a->pool < 0) {   // class pooling over compact rows (parts combined by an integer max: ReLU outputs only)
+    if (!a->hdr || !a->crow_c || a->act != 1) return DET6D_EINVAL;
   } else {
     if (a->pool != 0 && a->pool != 8 && a->pool != 16 && a->pool != 32) return DET6D_EINVAL;
     if (a->pool && (a->rows % a->pool)) return DET6D_EINVAL;

@@ -60,6 +60,12 @@ __device__ __forceinline__ int compact_out_row(int s, int qq, int kh) {
   if (s == 16) return (qq & 1) ? -1 : 8 * qq;
   return qq == 0 ? 0 : -1;
 }
+// pooled value of one part of a centre: plain store, or (bit 29 of the row tag: the centre's rows are cut into several
+// parts, compact.hip) integer atomic max on the non-negative post-ReLU value into the zeroed buffer
+__device__ __forceinline__ void compact_store(float *dst, float val, int tag) {
+  if (tag & 0x20000000) __hip_atomic_fetch_max(reinterpret_cast<int *>(dst), __builtin_bit_cast(int, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *dst = val;
+}
 // the four 4-row maxima of a lane -> pooled values of class s (in place; v[qq] valid where compact_out_row >= 0)
 __device__ __forceinline__ void compact_pool(float (&v)[4], int s) {
   if (s == 4) return;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     if (COMPACT) {
       in.row = *reinterpret_cast<const float4 *>(g.a + (size_t)p * 4);
       const int cj = g.crow_c[t * 32 + l31];
-      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x3fffffff) * g.ldctr;
+      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
       in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
       in.cnt0 = in.cnt1 = 0;
       const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
       if (COMPACT) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-          if (pend_oc[qq] >= 0) g.y[(size_t)(pend_oc[qq] & 0x3fffffff) * g.ldy + g.col0 + col] = pend[j][qq];
+          if (pend_oc[qq] >= 0) compact_store(g.y + (size_t)(pend_oc[qq] & 0x1fffffff) * g.ldy + g.col0 + col, pend[j][qq], pend_oc[qq]);
       } else if (NS == 32) {
         g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
       } else {
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
 #pragma unroll
       for (int s = 0; s < S1; ++s) xin[s] = src[2 * s];
       const int cj = g.crow_c[t * 32 + l31];
-      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x3fffffff) * g.ldctr;
+      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
       csub0 = kh ? c[1] : c[0];
       csub1 = kh ? 0.f : c[2];
       cnt0 = cnt1 = 0;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       if (COMPACT) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-          if (pend_oc[qq] >= 0) g.y[(size_t)(pend_oc[qq] & 0x3fffffff) * g.ldy + g.col0 + col] = pend[j][qq];
+          if (pend_oc[qq] >= 0) compact_store(g.y + (size_t)(pend_oc[qq] & 0x1fffffff) * g.ldy + g.col0 + col, pend[j][qq], pend_oc[qq]);
       } else if (NS == 32) {
         g.y[(size_t)pend_tile * g.ldy + g.col0 + col] = pend[j][0];
       } else {

@@ -221,9 +221,12 @@ class _PointnetSAModuleFSBase(nn.Module):
             else:
                 new_xyz = fused.gather_centres(xyz, sample_idx)
         m = new_xyz.shape[1]
-        pooled = torch.empty((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
-        if pooled.shape[1] != f['pooled_width']:
-            pooled[:, f['pooled_width']:].zero_()
+        if COMPACT_ROWS and fused.COMPACT_SPLIT:   # parts of a centre are combined by an atomic max into a zeroed buffer
+            pooled = torch.zeros((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
+        else:
+            pooled = torch.empty((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
+            if pooled.shape[1] != f['pooled_width']:
+                pooled[:, f['pooled_width']:].zero_()
         col = 0
         # neighbour search: shells [former, radius) when dilated, plain balls otherwise
         shells, former_radius = [], 0.0

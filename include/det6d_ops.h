@@ -337,9 +337,13 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  *   hdr (16) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
  *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment;
  *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row
- *                 (crow_c: bit 30 set for an empty ball, -1 on alignment rows). */
+ *                 (crow_c: bit 30 set for an empty ball, bit 29 for a centre cut into several parts, -1 on
+ *                 alignment rows).
+ * split != 0: a centre takes ceil(cnt / smin) * smin rows, cut along their binary digits into parts of descending
+ * size (20 = 16 + 4), each a group of its class; consumers combine the parts' maxima with an integer atomic max
+ * on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before the pooled layer runs. */
 int det6d_compact_rows_capacity(int total_centres, int ns);
-int det6d_compact_groups(int b, int n, int m, int ns, int smin, const int *cnt, const int *idx, int *hdr,
+int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,
                          int *crow_p, int *crow_c, det6d_stream_t stream);
 
 /* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-t() { GPU_MAX_HW_QUEUES=$1 python bench.py --cpu-scenes 0 --no-roofline --streams $2 --group $3 --prefetch $4 --sampler-streams $5 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('queues', sys.argv[1], 'main', sys.argv[2], 'group', sys.argv[3], 'prefetch', sys.argv[4], 'samp', sys.argv[5], 'prio', os.environ.get('DET6D_GROUP_PRIO'), d['value'], d['ms_per_step'])" $1 $2 $3 $4 $5; }
-t 24 16 4 3 6; t 24 16 4 4 6; t 24 16 4 6 6; t 24 16 8 3 6; t 24 16 4 4 4; t 24 18 4 4 5; t 24 14 4 4 6; t 24 16 2 6 6
-export DET6D_GROUP_PRIO=-1
-t 24 16 4 4 4; t 24 16 8 3 4; t 24 18 4 4 4
+timeout 1200 python -m pytest tests/test_compact_gpu.py tests/test_model_gpu.py tests/test_golden_gpu.py -x -q -m gpu 2>&1 | tail -5
+t() { python bench.py --cpu-scenes 0 --no-roofline 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('split', os.environ.get('DET6D_COMPACT_SPLIT'), d['value'], d['ms_per_step'])"; }
+t; DET6D_COMPACT_SPLIT=0 t; t; DET6D_COMPACT_SPLIT=0 t
+python scripts/gpu_linear_breakdown.py 2>/dev/null | tail -42

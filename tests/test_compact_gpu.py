@@ -33,18 +33,57 @@ def padded_query(rng, b, n, m, ns, p_empty=0.05, p_full=0.1):
     return cnt, idx
 
 
+def build_list(fused, cnt, idx, n, smin, split):
+    old = fused.COMPACT_SMIN, fused.COMPACT_SPLIT
+    fused.COMPACT_SMIN, fused.COMPACT_SPLIT = smin, split
+    try:
+        return fused.compact_groups(dev(cnt), dev(idx), n)
+    finally:
+        fused.COMPACT_SMIN, fused.COMPACT_SPLIT = old
+
+
+@pytest.mark.parametrize("b,n,m,ns,smin", [(2, 500, 300, 16, 4), (3, 900, 1000, 32, 4), (1, 64, 7, 32, 1), (2, 300, 513, 16, 2),
+                                           (8, 2048, 4096, 32, 4), (2, 100, 50, 8, 4), (1, 40, 33, 4, 4)])
+def test_split_groups_structure(b, n, m, ns, smin):
+    """split lists: ceil(cnt / smin) * smin rows per centre, cut along their binary digits into parts of descending
+    size; part of size S at slot offset (rows & ~(2S - 1)) lies in the class-S region, centres ascending"""
+    from de6d_amd.ops import fused
+    rng = np.random.default_rng(b * 1000 + m + ns + 5)
+    cnt, idx = padded_query(rng, b, n, m, ns)
+    cr = build_list(fused, cnt, idx, n, smin, True)
+    hdr, cp, cc = cr.hdr.cpu().numpy(), cr.crow_p.cpu().numpy(), cr.crow_c.cpu().numpy()
+    flat_cnt, flat_idx = cnt.reshape(-1), idx.reshape(-1, ns)
+    rows = (np.clip(flat_cnt, 1, ns) + smin - 1) // smin * smin
+    assert hdr[0] % 128 == 0 and hdr[7] == b * m and hdr[8] == np.minimum(cnt, ns).sum() and hdr[9] == rows.sum()
+    start = 0
+    for c in range(6):
+        s, end = 32 >> c, int(hdr[1 + c])
+        members = np.nonzero(rows & s)[0]
+        if len(members) == 0:
+            assert end == start
+            continue
+        assert end % 128 == 0 and start + len(members) * s <= end < start + len(members) * s + 128
+        off = rows[members] & ~(2 * s - 1)
+        region_c = cc[start:start + len(members) * s].reshape(-1, s)
+        region_p = cp[start:start + len(members) * s].reshape(-1, s)
+        np.testing.assert_array_equal(region_c & 0x1fffffff, np.repeat(members[:, None], s, 1))
+        np.testing.assert_array_equal((region_c >> 30) & 1, np.repeat((flat_cnt[members] == 0)[:, None], s, 1))
+        multi = (rows[members] & (rows[members] - 1)) != 0
+        np.testing.assert_array_equal((region_c >> 29) & 1, np.repeat(multi[:, None], s, 1))
+        want_p = np.stack([flat_idx[mm, o:o + s] for mm, o in zip(members, off)]) + (members // m * n)[:, None]
+        np.testing.assert_array_equal(region_p, want_p)
+        assert (cc[start + len(members) * s:end] == -1).all()
+        start = end
+    assert hdr[0] == start
+
+
 @pytest.mark.parametrize("b,n,m,ns,smin", [(2, 500, 300, 16, 4), (3, 900, 1000, 32, 4), (1, 64, 7, 32, 1), (2, 300, 513, 16, 2),
                                            (8, 2048, 4096, 32, 4), (2, 100, 50, 8, 4), (1, 40, 33, 4, 4)])
 def test_compact_groups_structure(b, n, m, ns, smin):
     from de6d_amd.ops import fused
     rng = np.random.default_rng(b * 1000 + m + ns)
     cnt, idx = padded_query(rng, b, n, m, ns)
-    old = fused.COMPACT_SMIN
-    fused.COMPACT_SMIN = smin
-    try:
-        cr = fused.compact_groups(dev(cnt), dev(idx), n)
-    finally:
-        fused.COMPACT_SMIN = old
+    cr = build_list(fused, cnt, idx, n, smin, False)
     hdr, cp, cc = cr.hdr.cpu().numpy(), cr.crow_p.cpu().numpy(), cr.crow_c.cpu().numpy()
     total = int(hdr[0])
     assert total % 128 == 0 and total <= cr.capacity and cr.capacity % 1024 == 0
@@ -94,8 +133,8 @@ def make_layers(rng, ld, c_in, widths):
                                                    (64, (64, 96, 128), 32, True), (1, (32, 32, 64), 32, False),
                                                    (128, (128, 128, 256), 16, False), (128, (128, 256, 256), 32, False),
                                                    (5, (24, 40, 72), 8, False), (256, (256, 512, 1024), 32, False)])
-@pytest.mark.parametrize("smin", [4, 1])
-def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, smin):
+@pytest.mark.parametrize("smin,split", [(4, True), (4, False), (1, False)])
+def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, smin, split):
     """gather + 3 x (GEMM, shift, ReLU) + mask + max-pool over the compact rows (register chain kernels and the
     three-GEMM route) == the oracle over ALL nsample rows"""
     from de6d_amd.ops import fused
@@ -110,12 +149,8 @@ def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, sm
     cnt, idx = padded_query(rng, b, n, m, ns)
     layers_np, layers_dev = make_layers(rng, ld, c_in, widths)
     out = torch.full((b * m, widths[2] + 3), -7.0, device="cuda")
-    old = fused.COMPACT_SMIN
-    fused.COMPACT_SMIN = smin
-    try:
-        cr = fused.compact_groups(dev(cnt), dev(idx), n)
-    finally:
-        fused.COMPACT_SMIN = old
+    out[:, 3:] = 0.0        # split lists combine the parts of a centre by an atomic max into a zeroed buffer
+    cr = build_list(fused, cnt, idx, n, smin, split)
     d_rows, d_ctr = dev(rows), dev(ctr)
     if chain:
         assert fused.chain_compact_eligible(ld, layers_dev)
@@ -140,7 +175,7 @@ def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, sm
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}])
+@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}, {'DET6D_COMPACT_SPLIT': '0'}])
 def test_model_parity_on_the_other_row_paths(env):
     """the whole-model bit-exact tests run on compact rows with the chain kernels by default; rerun a subset on the
     reference's dense row space and on the three-GEMM compact route (switches are read at import: child process)"""
