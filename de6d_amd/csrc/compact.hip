@@ -26,15 +26,16 @@ constexpr int kClasses = 6;
 
 // classes (bit c <-> s = 32 >> c) the rows of a centre with `cnt` hits are placed in.
 //   split = 0: one part, the next power of two >= max(cnt, smin);
-//   split = 1: ceil(cnt / smin) * smin rows, cut along their binary digits into parts of descending size (20 rows =
-//              16 + 4: slots 0..15 form a class-16 group, slots 16..19 a class-4 group); the pooled value of the
-//              centre is the maximum over its parts, combined by an integer atomic max on the (non-negative, post-ReLU)
-//              outputs (bit 29 of crow_c marks such rows; the pooled buffer is zeroed first).
+//   split = g > 0: up to g hits the same single part; beyond, ceil(cnt / g) * g rows, cut along their binary digits
+//              into parts of descending size (20 rows = 16 + 4: slots 0..15 form a class-16 group, slots 16..19 a
+//              class-4 group); the pooled value of the centre is the maximum over its parts, combined by an integer
+//              atomic max on the (non-negative, post-ReLU) outputs (bit 29 of crow_c marks such rows; the pooled
+//              buffer is zeroed first).  smin = 1, g = 4: singles and pairs are rows of their own, no atomics for them.
 __device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split, int *rows_out) {
   const int k = cnt < 1 ? 1 : (cnt > ns ? ns : cnt);
   int rows;
-  if (split) {
-    rows = (k + smin - 1) / smin * smin;
+  if (split > 0 && k > split) {
+    rows = (k + split - 1) / split * split;
   } else {
     rows = smin;
     while (rows < k) rows <<= 1;
@@ -168,11 +169,13 @@ DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int sp
   if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
   if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
   if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
+  if (split < 0 || (split & (split - 1)) || (split && split < smin)) return DET6D_EINVAL;
+  if (split > ns) split = ns;
   const int total = b * m;
   int blocks = det6d_divup(total, 256);   // every workgroup reads all counts once (prefix of its chunk): keep them few
   if (blocks > 128) blocks = 128;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split ? 1 : 0,
+  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split,
                      cnt, idx, hdr, crow_p, crow_c);
   return det6d_check_launch("det6d_compact_groups");
 }

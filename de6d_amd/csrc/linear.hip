@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   //   class 4: group = rows 8*qq + 4*kh .. +3, every lane writes its own four groups
   //   class 8 / 16 / 32: the lane^32 exchange completes the group; lanes of half 0 write group qq / qq>>1 / 0
   int pre_ctr[TM][4];
-  if (g.pool < 0) {
+  if (g.pool < 0 && pool >= 4) {
     const int khl = (tid & 63) >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -419,6 +419,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
             const float m = relu_act(q[qq] + sh, g.act);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pre_cnt[i][qq] > 0 ? m : 0.f), srd_y, voff,
                                                   (rbase / 8 + qq) * ldy4, 0);
+          }
+        }
+      }
+    }
+    return;
+  }
+  // compact rows, classes 1 and 2 (single hits / pairs: the cheap narrow groups): every accumulator (pair) is a
+  // group of its own; the row tags are fetched here
+  if (g.pool < 0 && pool < 4) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colb + wn * 32 * TN + 32 * j + l31;
+      const bool cok = col < N;
+      const float sh = (cok && g.shift) ? g.shift[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rbase = row0 + wm * 32 * TM + 32 * i;
+#pragma unroll
+        for (int e = 0; e < 16; e += 1) {
+          if (pool == 2 && (e & 1)) continue;
+          const float raw = pool == 2 ? d6_vmax(acc[i][j][e], acc[i][j][e + 1]) : acc[i][j][e];
+          const int cj = g.crow_c[rbase + (e & 3) + 8 * (e >> 2) + 4 * kh];
+          if (cok && cj >= 0) {
+            const float val = (cj & 0x40000000) ? 0.f : relu_act(raw + sh, g.act);
+            float *dst = g.y + (size_t)(cj & 0x1fffffff) * g.ldy + g.col0 + col;
+            if (cj & 0x20000000) __hip_atomic_fetch_max(reinterpret_cast<int *>(dst), __builtin_bit_cast(int, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = val;
           }
         }
       }

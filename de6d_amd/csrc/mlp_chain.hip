@@ -54,6 +54,7 @@ __device__ __forceinline__ int compact_class(int row0, int h1, int h2, int h3, i
 // row (inside a 32-row tile) whose centre owns pooled value qq of a lane in half kh, -1: another lane writes it.
 // A lane holds rows 8*qq + 4*kh + (0..3); class 4 groups end inside the lane, wider groups after the lane^32 exchange.
 __device__ __forceinline__ int compact_out_row(int s, int qq, int kh) {
+  if (s < 4) return -1;          // classes 1, 2: stored at once by compact_store_small
   if (s == 4) return 8 * qq + 4 * kh;
   if (kh) return -1;
   if (s == 8) return 8 * qq;
@@ -65,6 +66,16 @@ __device__ __forceinline__ int compact_out_row(int s, int qq, int kh) {
 __device__ __forceinline__ void compact_store(float *dst, float val, int tag) {
   if (tag & 0x20000000) __hip_atomic_fetch_max(reinterpret_cast<int *>(dst), __builtin_bit_cast(int, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *dst = val;
+}
+// classes 1 and 2: every accumulator (pair) of a 32x32 tile is a group of its own: stored at once (no pending slot)
+__device__ __forceinline__ void compact_store_small(const ChainArgs &g, const f32x16 &o, int s, int tile, int kh, int col, float sh) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (s == 2 && (e & 1)) continue;
+    const float raw = s == 2 ? d6_vmax(o[e], o[e + 1 < 16 ? e + 1 : e]) : o[e];
+    const int tag = g.crow_c[tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+    if (tag >= 0) compact_store(g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + col, (tag & 0x40000000) ? 0.f : d6_relu(raw + sh), tag);
+  }
 }
 // the four 4-row maxima of a lane -> pooled values of class s (in place; v[qq] valid where compact_out_row >= 0)
 __device__ __forceinline__ void compact_pool(float (&v)[4], int s) {
@@ -377,7 +388,14 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
       if (COMPACT) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
-        compact_pool(q, compact_class(tile * 32, h1, h2, h3, h4, h5));
+        const int sc = compact_class(tile * 32, h1, h2, h3, h4, h5);
+        if (sc < 4) {
+          compact_store_small(g, o, sc, tile, kh, col, sh3[j]);
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) pend[j][qq] = 0.f;
+          continue;
+        }
+        compact_pool(q, sc);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) pend[j][qq] = (cur.oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]);
         continue;
@@ -425,6 +443,8 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   float *W2 = W1 + (K1 + 2) * C1;           // (C1 + 2) x C2
   float *W3 = W2 + (C1 + 2) * C2;           // C2 x C3
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  // compact lists: the grid is sized for the capacity; workgroups without a live tile leave before staging 66-92 KB of weights
+  if (COMPACT && (int)(blockIdx.x * (blockDim.x >> 6)) >= g.hdr[0] / 32) return;
   // staging with 16-byte loads (all leading dimensions and widths are multiples of 4)
   auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols) {
     const int c4 = cols / 4;
@@ -570,7 +590,14 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       if (COMPACT) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
-        compact_pool(q, compact_class(tile * 32, h1, h2, h3, h4, h5));
+        const int sc = compact_class(tile * 32, h1, h2, h3, h4, h5);
+        if (sc < 4) {
+          compact_store_small(g, o, sc, tile, kh, 32 * j + l31, sh3[j]);
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) pend[j][qq] = 0.f;
+          continue;
+        }
+        compact_pool(q, sc);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) pend[j][qq] = (my_oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]);
         continue;

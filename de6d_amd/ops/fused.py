@@ -85,12 +85,12 @@ class CompactRows:
         self.hdr, self.crow_p, self.crow_c, self.capacity, self.ns = hdr, crow_p, crow_c, capacity, ns
 
 
-#: smallest row class of the compact lists (the GEMM / chain epilogues pool classes 4, 8, 16, 32)
-COMPACT_SMIN = int(os.environ.get('DET6D_COMPACT_SMIN', '4'))
-COMPACT_SMALL_CLASSES = False
-#: a centre's rows are cut into power-of-two parts (20 = 16 + 4) whose maxima are combined by an atomic max, instead
-#: of being padded to the next power of two; the pooled buffer must be zeroed first (DET6D_COMPACT_SPLIT=0: padding)
-COMPACT_SPLIT = os.environ.get('DET6D_COMPACT_SPLIT', '1') != '0'
+#: smallest row class of the compact lists (1, 2 or 4)
+COMPACT_SMIN = int(os.environ.get('DET6D_COMPACT_SMIN', '1'))
+COMPACT_SMALL_CLASSES = True
+#: centres with more than g hits take ceil(cnt / g) * g rows cut into power-of-two parts (20 = 16 + 4) whose maxima are
+#: combined by an atomic max, instead of being padded to the next power of two; the pooled buffer must be zeroed first
+COMPACT_SPLIT = int(os.environ.get('DET6D_COMPACT_SPLIT', '1'))   # the granule g (0: padding to the next power of two)
 
 
 def compact_groups(cnt, idx, n):
@@ -101,7 +101,7 @@ def compact_groups(cnt, idx, n):
     hdr = torch.empty((16,), dtype=torch.int32, device=idx.device)
     crow_p = torch.empty((cap,), dtype=torch.int32, device=idx.device)
     crow_c = torch.empty((cap,), dtype=torch.int32, device=idx.device)
-    L.call("det6d_compact_groups", b, n, m, ns, min(COMPACT_SMIN, ns), 1 if COMPACT_SPLIT else 0, L.ptr(cnt), L.ptr(idx),
+    L.call("det6d_compact_groups", b, n, m, ns, min(COMPACT_SMIN, ns), max(COMPACT_SPLIT, min(COMPACT_SMIN, ns)) if COMPACT_SPLIT else 0, L.ptr(cnt), L.ptr(idx),
            L.ptr(hdr), L.ptr(crow_p), L.ptr(crow_c), L.stream_ptr())
     return CompactRows(hdr, crow_p, crow_c, cap, ns)
 

@@ -339,9 +339,10 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row
  *                 (crow_c: bit 30 set for an empty ball, bit 29 for a centre cut into several parts, -1 on
  *                 alignment rows).
- * split != 0: a centre takes ceil(cnt / smin) * smin rows, cut along their binary digits into parts of descending
- * size (20 = 16 + 4), each a group of its class; consumers combine the parts' maxima with an integer atomic max
- * on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before the pooled layer runs. */
+ * split = g > 0 (a power of two >= smin): a centre with more than g hits takes ceil(cnt / g) * g rows, cut along their
+ * binary digits into parts of descending size (20 = 16 + 4), each a group of its class; consumers combine the parts'
+ * maxima with an integer atomic max on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before
+ * the pooled layer runs.  Centres with <= g hits stay one part of the next power of two >= max(cnt, smin). */
 int det6d_compact_rows_capacity(int total_centres, int ns);
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,
                          int *crow_p, int *crow_c, det6d_stream_t stream);

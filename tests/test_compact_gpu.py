@@ -45,15 +45,19 @@ def build_list(fused, cnt, idx, n, smin, split):
 @pytest.mark.parametrize("b,n,m,ns,smin", [(2, 500, 300, 16, 4), (3, 900, 1000, 32, 4), (1, 64, 7, 32, 1), (2, 300, 513, 16, 2),
                                            (8, 2048, 4096, 32, 4), (2, 100, 50, 8, 4), (1, 40, 33, 4, 4)])
 def test_split_groups_structure(b, n, m, ns, smin):
-    """split lists: ceil(cnt / smin) * smin rows per centre, cut along their binary digits into parts of descending
-    size; part of size S at slot offset (rows & ~(2S - 1)) lies in the class-S region, centres ascending"""
+    """split lists (granule 4): up to 4 hits one part of the next power of two >= smin, beyond that ceil(cnt / 4) * 4
+    rows cut along their binary digits into parts of descending size; part of size S at slot offset
+    (rows & ~(2S - 1)) lies in the class-S region, centres ascending"""
     from de6d_amd.ops import fused
     rng = np.random.default_rng(b * 1000 + m + ns + 5)
     cnt, idx = padded_query(rng, b, n, m, ns)
-    cr = build_list(fused, cnt, idx, n, smin, True)
+    gran = min(4, ns)
+    cr = build_list(fused, cnt, idx, n, smin, gran)
     hdr, cp, cc = cr.hdr.cpu().numpy(), cr.crow_p.cpu().numpy(), cr.crow_c.cpu().numpy()
     flat_cnt, flat_idx = cnt.reshape(-1), idx.reshape(-1, ns)
-    rows = (np.clip(flat_cnt, 1, ns) + smin - 1) // smin * smin
+    kk = np.clip(flat_cnt, 1, ns)
+    pow2 = np.maximum(smin, 2 ** np.ceil(np.log2(kk)).astype(np.int64))
+    rows = np.where(kk > gran, (kk + gran - 1) // gran * gran, pow2)
     assert hdr[0] % 128 == 0 and hdr[7] == b * m and hdr[8] == np.minimum(cnt, ns).sum() and hdr[9] == rows.sum()
     start = 0
     for c in range(6):
@@ -83,7 +87,7 @@ def test_compact_groups_structure(b, n, m, ns, smin):
     from de6d_amd.ops import fused
     rng = np.random.default_rng(b * 1000 + m + ns)
     cnt, idx = padded_query(rng, b, n, m, ns)
-    cr = build_list(fused, cnt, idx, n, smin, False)
+    cr = build_list(fused, cnt, idx, n, smin, 0)
     hdr, cp, cc = cr.hdr.cpu().numpy(), cr.crow_p.cpu().numpy(), cr.crow_c.cpu().numpy()
     total = int(hdr[0])
     assert total % 128 == 0 and total <= cr.capacity and cr.capacity % 1024 == 0
@@ -133,7 +137,7 @@ def make_layers(rng, ld, c_in, widths):
                                                    (64, (64, 96, 128), 32, True), (1, (32, 32, 64), 32, False),
                                                    (128, (128, 128, 256), 16, False), (128, (128, 256, 256), 32, False),
                                                    (5, (24, 40, 72), 8, False), (256, (256, 512, 1024), 32, False)])
-@pytest.mark.parametrize("smin,split", [(4, True), (4, False), (1, False)])
+@pytest.mark.parametrize("smin,split", [(4, 4), (4, 0), (1, 0), (1, 4), (1, 1), (2, 2), (2, 8)])
 def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, smin, split):
     """gather + 3 x (GEMM, shift, ReLU) + mask + max-pool over the compact rows (register chain kernels and the
     three-GEMM route) == the oracle over ALL nsample rows"""
@@ -175,7 +179,7 @@ def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, sm
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}, {'DET6D_COMPACT_SPLIT': '0'}])
+@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}, {'DET6D_COMPACT_SPLIT': '0'}, {'DET6D_COMPACT_SMIN': '4'}, {'DET6D_COMPACT_SPLIT': '1'}])
 def test_model_parity_on_the_other_row_paths(env):
     """the whole-model bit-exact tests run on compact rows with the chain kernels by default; rerun a subset on the
     reference's dense row space and on the three-GEMM compact route (switches are read at import: child process)"""
