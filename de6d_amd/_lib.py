@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_erro
                                                   "det6d_postprocess_workspace_bytes",
                                                   "det6d_ball_query_grid_workspace_bytes",
                                                   "det6d_prepare_points_workspace_bytes",
-                                                  "det6d_compact_rows_capacity"])
+                                                  "det6d_compact_rows_capacity", "det6d_compact_hdr_ints"])
 
 _lib = None
 
@@ -124,6 +124,8 @@ def lib():
         handle.det6d_ball_query_grid_workspace_bytes.restype = c_int64
         handle.det6d_prepare_points_workspace_bytes.argtypes = [c_int, c_int]
         handle.det6d_prepare_points_workspace_bytes.restype = c_int64
+        handle.det6d_compact_hdr_ints.argtypes = [c_int]
+        handle.det6d_compact_hdr_ints.restype = c_int
         handle.det6d_compact_rows_capacity.argtypes = [c_int, c_int]
         handle.det6d_compact_rows_capacity.restype = c_int
         handle.det6d_postprocess_workspace_bytes.argtypes = [c_int]

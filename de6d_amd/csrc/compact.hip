@@ -48,42 +48,63 @@ __device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split, in
   return mask;
 }
 
-__global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, int m, int ns, int smin, int split,
-                                                             const int *__restrict__ cnt, const int *__restrict__ idx,
-                                                             int *__restrict__ hdr, int *__restrict__ crow_p,
-                                                             int *__restrict__ crow_c) {
-  __shared__ int h_all[kClasses], h_before[kClasses], h_real;
+// pass 1: parts per class (and information rows) of every block of 256 centres -> table[block][kClasses + 1]
+__global__ __launch_bounds__(256) void compact_count_kernel(int total, int ns, int smin, int split, const int *__restrict__ cnt,
+                                                            int *__restrict__ table) {
+  __shared__ int acc[kClasses + 1];
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  if (tid <= kClasses) acc[tid] = 0;
+  __syncthreads();
+  int rows = 0, k = 0;
+  const int mask = i < total ? parts_of(k = cnt[i], ns, smin, split, &rows) : 0;
+  const int real = i < total ? (k < 0 ? 0 : (k < ns ? k : ns)) : 0;
+#pragma unroll
+  for (int cc = 0; cc < kClasses; ++cc) {
+    const int c = __popcll(__ballot((mask >> cc) & 1));
+    if ((tid & 63) == 0 && c) atomicAdd(&acc[cc], c);
+  }
+  int r = real;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+  if ((tid & 63) == 0 && r) atomicAdd(&acc[kClasses], r);
+  __syncthreads();
+  if (tid <= kClasses) table[blockIdx.x * (kClasses + 1) + tid] = acc[tid];
+}
+
+// pass 2: one workgroup per block of 256 centres: region starts and the block's first row per class from the table,
+// then ordered placement (ballot ranks per class), one thread per (centre, slot) for the row writes
+__global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, int m, int ns, int smin, int split, int nblk,
+                                                            const int *__restrict__ cnt, const int *__restrict__ idx,
+                                                            const int *__restrict__ table, int *__restrict__ hdr,
+                                                            int *__restrict__ crow_p, int *__restrict__ crow_c) {
+  __shared__ int h_all[kClasses + 1], h_before[kClasses];
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
   __shared__ int r0_s[256][kClasses], rows_s[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = (((total + gridDim.x - 1) / gridDim.x) + 255) & ~255;
-  const int c_lo = blockIdx.x * chunk;
-  const int c_hi = c_lo + chunk < total ? c_lo + chunk : total;
-  if (tid < kClasses) { h_all[tid] = 0; h_before[tid] = 0; }
-  if (tid == 0) h_real = 0;
+  if (tid <= kClasses) h_all[tid] = 0;
+  if (tid < kClasses) h_before[tid] = 0;
   __syncthreads();
-  {   // class histogram of the whole batch and of the centres before this workgroup's chunk
-    int la[kClasses], lb[kClasses], real = 0;
+  {
+    int la[kClasses + 1], lb[kClasses];
 #pragma unroll
-    for (int c = 0; c < kClasses; ++c) la[c] = lb[c] = 0;
-    for (int i = tid; i < total; i += 256) {
-      const int k = cnt[i];
-      int rows;
-      const int mask = parts_of(k, ns, smin, split, &rows);
-      real += k < ns ? k : ns;
+    for (int c = 0; c <= kClasses; ++c) la[c] = 0;
 #pragma unroll
-      for (int cc = 0; cc < kClasses; ++cc) {
-        la[cc] += (mask >> cc) & 1;
-        lb[cc] += ((mask >> cc) & 1) & (i < c_lo);
+    for (int c = 0; c < kClasses; ++c) lb[c] = 0;
+    for (int bk = tid; bk < nblk; bk += 256) {
+#pragma unroll
+      for (int c = 0; c <= kClasses; ++c) {
+        const int v = table[bk * (kClasses + 1) + c];
+        la[c] += v;
+        if (c < kClasses && bk < (int)blockIdx.x) lb[c] += v;
       }
     }
 #pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
+    for (int c = 0; c <= kClasses; ++c)
       if (la[c]) atomicAdd(&h_all[c], la[c]);
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c)
       if (lb[c]) atomicAdd(&h_before[c], lb[c]);
-    }
-    if (blockIdx.x == 0 && real) atomicAdd(&h_real, real);
   }
   __syncthreads();
   if (tid == 0) {
@@ -99,7 +120,7 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
       hdr[0] = r;
       for (int c = 0; c < kClasses; ++c) hdr[1 + c] = c + 1 < kClasses ? start[c + 1] : r;
       hdr[7] = total;
-      hdr[8] = h_real;
+      hdr[8] = h_all[kClasses];
       hdr[9] = unaligned;
     }
   }
@@ -110,51 +131,44 @@ __global__ __launch_bounds__(256) void compact_groups_kernel(int total, int n, i
       for (int r = e + tid; r < start[c + 1]; r += 256) { crow_p[r] = 0; crow_c[r] = -1; }
     }
   }
-  // ---- ordered placement of this chunk, 256 centres at a time: first row of every part of every centre into
-  //      LDS (ballot ranks per class), then one thread per (centre, slot) so that idx is read and the rows are
-  //      written with consecutive lanes on consecutive words ----
-  for (int i0 = c_lo; i0 < c_hi; i0 += 256) {
-    const int i = i0 + tid;
-    const bool ok = i < c_hi;
-    int rows = 0;
-    const int mask = ok ? parts_of(cnt[i], ns, smin, split, &rows) : 0;
-    int rank[kClasses];
+  const int i0 = blockIdx.x * 256, i = i0 + tid;
+  const bool ok = i < total;
+  int rows = 0;
+  const int mask = ok ? parts_of(cnt[i], ns, smin, split, &rows) : 0;
+  int rank[kClasses];
 #pragma unroll
-    for (int cc = 0; cc < kClasses; ++cc) {
-      const unsigned long long mk = __ballot((mask >> cc) & 1);
-      rank[cc] = __popcll(mk & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_cnt[wave][cc] = __popcll(mk);
-    }
-    __syncthreads();
-    rows_s[tid] = rows;
+  for (int cc = 0; cc < kClasses; ++cc) {
+    const unsigned long long mk = __ballot((mask >> cc) & 1);
+    rank[cc] = __popcll(mk & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave][cc] = __popcll(mk);
+  }
+  __syncthreads();
+  rows_s[tid] = rows;
 #pragma unroll
-    for (int cc = 0; cc < kClasses; ++cc) {
-      int before = 0;
-      for (int w = 0; w < wave; ++w) before += wave_cnt[w][cc];
-      r0_s[tid][cc] = base[cc] + (before + rank[cc]) * (32 >> cc);
-    }
-    __syncthreads();
-    if (tid < kClasses) base[tid] += (wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]) * (32 >> tid);
-    const int lg = 31 - __builtin_clz(ns);
-    for (int e = tid; e < 256 * ns; e += 256) {
-      const int ci = e >> lg, t = e & (ns - 1);
-      const int rw = rows_s[ci];
-      if (t < rw) {
-        const int cg = i0 + ci;
-        int row = 0;
+  for (int cc = 0; cc < kClasses; ++cc) {
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][cc];
+    r0_s[tid][cc] = base[cc] + (before + rank[cc]) * (32 >> cc);
+  }
+  __syncthreads();
+  const int lg = 31 - __builtin_clz(ns);
+  for (int e = tid; e < 256 * ns; e += 256) {
+    const int ci = e >> lg, t = e & (ns - 1);
+    const int rw = rows_s[ci];
+    if (t < rw) {
+      const int cg = i0 + ci;
+      int row = 0;
 #pragma unroll
-        for (int cc = 0; cc < kClasses; ++cc) {   // the part that holds slot t: parts in descending size
-          const int sz = 32 >> cc, off = rw & ~(2 * sz - 1);
-          if ((rw & sz) && t >= off && t < off + sz) row = r0_s[ci][cc] + (t - off);
-        }
-        int tag = cg;
-        if (cnt[cg] <= 0) tag |= 0x40000000;          // empty ball: pooled value 0
-        if (rw & (rw - 1)) tag |= 0x20000000;          // several parts: combine with an atomic max
-        crow_p[row] = (cg / m) * n + idx[(size_t)cg * ns + t];
-        crow_c[row] = tag;
+      for (int cc = 0; cc < kClasses; ++cc) {   // the part that holds slot t: parts in descending size
+        const int sz = 32 >> cc, off = rw & ~(2 * sz - 1);
+        if ((rw & sz) && t >= off && t < off + sz) row = r0_s[ci][cc] + (t - off);
       }
+      int tag = cg;
+      if (cnt[cg] <= 0) tag |= 0x40000000;          // empty ball: pooled value 0
+      if (rw & (rw - 1)) tag |= 0x20000000;          // several parts: combine with an atomic max
+      crow_p[row] = (cg / m) * n + idx[(size_t)cg * ns + t];
+      crow_c[row] = tag;
     }
-    __syncthreads();
   }
 }
 
@@ -164,6 +178,8 @@ DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
   return (total_centres * ns + kClasses * 128 + 1023) & ~1023;   // a multiple of 8 row tiles: keeps the XCD-aware tile order
 }
 
+DET6D_API int det6d_compact_hdr_ints(int total_centres) { return 16 + (kClasses + 1) * (det6d_divup(total_centres, 256) + 1); }
+
 DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx,
                                    int *hdr, int *crow_p, int *crow_c, det6d_stream_t stream) {
   if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
@@ -172,10 +188,10 @@ DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int sp
   if (split < 0 || (split & (split - 1)) || (split && split < smin)) return DET6D_EINVAL;
   if (split > ns) split = ns;
   const int total = b * m;
-  int blocks = det6d_divup(total, 256);   // every workgroup reads all counts once (prefix of its chunk): keep them few
-  if (blocks > 128) blocks = 128;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(compact_groups_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split,
-                     cnt, idx, hdr, crow_p, crow_c);
+  const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
+  int *table = hdr + 16;   // per-block counts behind the 16 header words (det6d_compact_hdr_ints)
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, ns, smin, split, cnt, table);
+  hipLaunchKernelGGL(compact_place_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split, nblk, cnt,
+                     idx, table, hdr, crow_p, crow_c);
   return det6d_check_launch("det6d_compact_groups");
 }

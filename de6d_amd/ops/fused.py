@@ -98,7 +98,7 @@ def compact_groups(cnt, idx, n):
     L.require_cuda(cnt, idx)
     b, m, ns = idx.shape
     cap = int(L.lib().det6d_compact_rows_capacity(b * m, ns))
-    hdr = torch.empty((16,), dtype=torch.int32, device=idx.device)
+    hdr = torch.empty((int(L.lib().det6d_compact_hdr_ints(b * m)),), dtype=torch.int32, device=idx.device)
     crow_p = torch.empty((cap,), dtype=torch.int32, device=idx.device)
     crow_c = torch.empty((cap,), dtype=torch.int32, device=idx.device)
     L.call("det6d_compact_groups", b, n, m, ns, min(COMPACT_SMIN, ns), max(COMPACT_SPLIT, min(COMPACT_SMIN, ns)) if COMPACT_SPLIT else 0, L.ptr(cnt), L.ptr(idx),

@@ -334,7 +334,7 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  * and is followed by a max over the nsample rows (pointnet2_modules.py:462-467): evaluating only the first
  * s = max(smin, 2^ceil(log2 cnt)) slots of every centre gives the same pooled features bit for bit.
  *   cnt (B*m), idx (B,m,ns) as written by the ball queries;  ns, smin powers of two, smin <= ns <= 32;
- *   hdr (16) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
+ *   hdr (det6d_compact_hdr_ints(B*m)) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
  *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment;
  *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row
  *                 (crow_c: bit 30 set for an empty ball, bit 29 for a centre cut into several parts, -1 on
@@ -344,6 +344,7 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  * maxima with an integer atomic max on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before
  * the pooled layer runs.  Centres with <= g hits stay one part of the next power of two >= max(cnt, smin). */
 int det6d_compact_rows_capacity(int total_centres, int ns);
+int det6d_compact_hdr_ints(int total_centres);   /* ints the hdr buffer must hold (16 header words + scratch) */
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,
                          int *crow_p, int *crow_c, det6d_stream_t stream);
 
