@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_compact_gpu.py tests/test_model_gpu.py -x -q -m gpu 2>&1 | tail -3
-t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print(sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
-t; t; t --streams 14; t --streams 18 ; t --prefetch 3; t --prefetch 5
+t() { python scripts/gpu_whatif2.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('nofps', sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
+t; t --streams 12; t --streams 8
