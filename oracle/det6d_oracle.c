@@ -527,7 +527,111 @@ typedef struct det6d_linear_args {
   const float *ctr; int ldctr;
   int pool;
   const int *cnt;
+  const int *hdr, *crow_p, *crow_c;   /* compact row lists (det6d_oracle_compact_groups) */
 } det6d_linear_args;
+
+/* Compact row lists: plain sequential restatement of de6d_amd/csrc/compact.hip (this is a data structure of the
+ * BUILD, not of the reference: the reference evaluates all nsample rows, ball_query_gpu.cu:75-90 pads them with
+ * repetitions of the first cnt hits; the parity tests compare the compact path with this oracle's DENSE rows). */
+ORACLE_API int det6d_oracle_compact_rows_capacity(int total_centres, int ns) {
+  return (total_centres * ns + 6 * 128 + 1023) & ~1023;
+}
+ORACLE_API int det6d_oracle_compact_hdr_ints(int total_centres) { return 16 + 7 * ((total_centres + 255) / 256 + 1); }
+static int compact_rows_of(int cnt, int ns, int smin, int split) {
+  const int k = cnt < 1 ? 1 : (cnt > ns ? ns : cnt);
+  if (split > 0 && k > split) return (k + split - 1) / split * split;
+  int rows = smin;
+  while (rows < k) rows <<= 1;
+  return rows;
+}
+ORACLE_API int det6d_oracle_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt,
+                                           const int *idx, int *hdr, int *crow_p, int *crow_c) {
+  const int total = b * m;
+  if (split > ns) split = ns;
+  int count[6] = {0, 0, 0, 0, 0, 0}, start[7], next[6], real = 0, unaligned = 0;
+  for (int i = 0; i < total; ++i) {
+    const int rows = compact_rows_of(cnt[i], ns, smin, split);
+    for (int c = 0; c < 6; ++c) count[c] += (rows & (32 >> c)) != 0;
+    real += cnt[i] < ns ? (cnt[i] < 0 ? 0 : cnt[i]) : ns;
+  }
+  int r = 0;
+  for (int c = 0; c < 6; ++c) {
+    start[c] = next[c] = r;
+    unaligned += count[c] * (32 >> c);
+    r = (r + count[c] * (32 >> c) + 127) & ~127;
+  }
+  start[6] = r;
+  hdr[0] = r;
+  for (int c = 0; c < 6; ++c) hdr[1 + c] = start[c + 1];
+  hdr[7] = total; hdr[8] = real; hdr[9] = unaligned;
+  for (int c = 0; c < 6; ++c)
+    for (int q = start[c] + count[c] * (32 >> c); q < start[c + 1]; ++q) { crow_p[q] = 0; crow_c[q] = -1; }
+  for (int i = 0; i < total; ++i) {
+    const int rows = compact_rows_of(cnt[i], ns, smin, split);
+    int tag = i;
+    if (cnt[i] <= 0) tag |= 0x40000000;
+    if (rows & (rows - 1)) tag |= 0x20000000;
+    for (int c = 0; c < 6; ++c) {
+      const int sz = 32 >> c;
+      if (!(rows & sz)) continue;
+      const int off = rows & ~(2 * sz - 1);
+      for (int t = 0; t < sz; ++t) {
+        crow_p[next[c] + t] = (i / m) * n + idx[(size_t)i * ns + off + t];
+        crow_c[next[c] + t] = tag;
+      }
+      next[c] += sz;
+    }
+  }
+  return 0;
+}
+
+/* det6d_linear over a compact row list: rows = hdr[0]; mode 2 gathers through crow_p / crow_c; pool = -1 takes the
+ * maximum over the rows of every centre (empty balls -> 0): a centre in ONE part overwrites y, a centre cut into
+ * several parts is max-combined with what y holds (the caller zeroes it), like the kernels' atomic max. */
+static int oracle_linear_compact(const det6d_linear_args *g) {
+  const int K = g->k, N = g->ncols, R = g->hdr[0], centres = g->hdr[7];
+  float *arow = (float *)malloc(sizeof(float) * (K > 0 ? K : 1));
+  float *acc = (float *)malloc(sizeof(float) * N);
+  char *seen = (char *)calloc((size_t)centres + 1, 1);
+  for (int r = 0; r < R; ++r) {
+    const int tag = (g->mode == 2 || g->pool < 0) ? g->crow_c[r] : 0;
+    if (tag < 0) continue;   /* alignment row */
+    const int cj = tag & 0x1fffffff;
+    if (g->mode == 2) {
+      const float *src = g->a + (size_t)g->crow_p[r] * g->lda;
+      const float *c = g->ctr + (size_t)cj * g->ldctr;
+      for (int k = 0; k < K; ++k) arow[k] = k < 3 ? src[k] - c[k] : src[k];
+    } else {
+      const float *src = g->a + (size_t)r * g->lda;
+      for (int k = 0; k < K; ++k) arow[k] = src[k];
+    }
+    for (int c = 0; c < N; ++c) acc[c] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float av = arow[k];
+      const float *wr = g->w + (size_t)k * g->ldw;
+      for (int c = 0; c < N; ++c) acc[c] = D6_FMA(av, wr[c], acc[c]);
+    }
+    for (int c = 0; c < N; ++c) {
+      float v = g->shift ? acc[c] + g->shift[c] : acc[c];
+      if (g->act == 1) v = v > 0.f ? v : 0.f;
+      acc[c] = v;
+    }
+    if (g->pool < 0) {
+      float *dst = g->y + (size_t)cj * g->ldy + g->col0;
+      const int empty = (tag & 0x40000000) != 0, multi = (tag & 0x20000000) != 0;
+      for (int c = 0; c < N; ++c) {
+        const float v = empty ? 0.f : acc[c];
+        dst[c] = (!multi && !seen[cj]) ? v : (v > dst[c] ? v : dst[c]);
+      }
+      seen[cj] = 1;
+    } else {
+      float *dst = g->y + (size_t)r * g->ldy + g->col0;
+      for (int c = 0; c < N; ++c) dst[c] = acc[c];
+    }
+  }
+  free(arow); free(acc); free(seen);
+  return 0;
+}
 
 /* Conv(1x1, bias=False) -> BatchNorm(eval) -> ReLU with BN folded into W/shift
  * (pointnet2_modules.py:561-568), grouping (pointnet2_utils.py:449-455), mask + max-pool
@@ -535,6 +639,7 @@ typedef struct det6d_linear_args {
  * then `+ shift`, then ReLU — the exact arithmetic of v_mfma_f32_32x32x2_f32. */
 ORACLE_API int det6d_oracle_linear(const det6d_linear_args *g) {
   const int K = g->k, N = g->ncols;
+  if (g->hdr) return oracle_linear_compact(g);
   if (g->pool && (g->rows % g->pool)) return -1;
 #pragma omp parallel
   {
@@ -608,6 +713,31 @@ ORACLE_API int det6d_oracle_mlp_chain3(int rows, int n, int m, int ns, const flo
   memset(&g, 0, sizeof(g));
   g.mode = 0; g.rows = rows; g.k = c2; g.ncols = c3; g.a = h2; g.lda = c2; g.w = w3; g.ldw = ldw3; g.shift = s3;
   g.act = 1; g.y = y; g.ldy = ldy; g.col0 = col0; g.pool = ns; g.cnt = cnt;
+  const int rc = det6d_oracle_linear(&g);
+  free(h1); free(h2);
+  return rc;
+}
+
+/* the same chain over a compact row list: by definition the three-call sequence */
+ORACLE_API int det6d_oracle_mlp_chain3_compact(int capacity, const int *hdr, const int *crow_p, const int *crow_c,
+                                               const float *a, int lda, const float *ctr, int ldctr, const float *w1,
+                                               int ldw1, const float *s1, int c1, const float *w2, int ldw2,
+                                               const float *s2, int c2, const float *w3, int ldw3, const float *s3,
+                                               int c3, float *y, int ldy, int col0) {
+  float *h1 = (float *)calloc((size_t)capacity * c1 + 1, sizeof(float));
+  float *h2 = (float *)calloc((size_t)capacity * c2 + 1, sizeof(float));
+  det6d_linear_args g;
+  memset(&g, 0, sizeof(g));
+  g.mode = 2; g.rows = capacity; g.k = lda; g.ncols = c1; g.a = a; g.lda = lda; g.w = w1; g.ldw = ldw1; g.shift = s1;
+  g.act = 1; g.y = h1; g.ldy = c1; g.ctr = ctr; g.ldctr = ldctr; g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
+  det6d_oracle_linear(&g);
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = capacity; g.k = c1; g.ncols = c2; g.a = h1; g.lda = c1; g.w = w2; g.ldw = ldw2; g.shift = s2;
+  g.act = 1; g.y = h2; g.ldy = c2; g.hdr = hdr;
+  det6d_oracle_linear(&g);
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = capacity; g.k = c2; g.ncols = c3; g.a = h2; g.lda = c2; g.w = w3; g.ldw = ldw3; g.shift = s3;
+  g.act = 1; g.y = y; g.ldy = ldy; g.col0 = col0; g.pool = -1; g.hdr = hdr; g.crow_c = crow_c;
   const int rc = det6d_oracle_linear(&g);
   free(h1); free(h2);
   return rc;

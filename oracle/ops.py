@@ -226,7 +226,35 @@ class _LinearArgs(ctypes.Structure):
                 ("idx", _ip),
                 ("ctr", _fp), ("ldctr", _c_int),
                 ("pool", _c_int),
-                ("cnt", _ip)]
+                ("cnt", _ip),
+                ("hdr", _ip), ("crow_p", _ip), ("crow_c", _ip)]
+
+
+def compact_groups(cnt, idx, n, smin=1, split=1):
+    """sequential restatement of the compact row lists (csrc/compact.hip): returns hdr, crow_p, crow_c"""
+    cnt, idx = _i(cnt), _i(idx)
+    b, m, ns = idx.shape
+    cap = int(lib().det6d_oracle_compact_rows_capacity(b * m, ns))
+    hdr = np.zeros(int(lib().det6d_oracle_compact_hdr_ints(b * m)), np.int32)
+    crow_p, crow_c = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    rc = lib().det6d_oracle_compact_groups(b, n, m, ns, smin, split, _pi(cnt), _pi(idx), _pi(hdr), _pi(crow_p), _pi(crow_c))
+    assert rc == 0
+    return hdr, crow_p, crow_c
+
+
+def mlp_chain3_compact(rows_pts, lists, ctr, layers, out, col0=0):
+    """three pointwise layers + max over every centre's rows on a compact list (hdr, crow_p, crow_c);
+    layers = [(W, shift)] x 3 with the true widths; out must be zeroed where centres have several parts"""
+    hdr, crow_p, crow_c = lists
+    a, ctr = _f(rows_pts), _f(ctr)
+    ws = [(_f(w), _f(s)) for w, s in layers]
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    rc = lib().det6d_oracle_mlp_chain3_compact(
+        len(crow_p), _pi(hdr), _pi(crow_p), _pi(crow_c), _pf(a), a.shape[-1], _pf(ctr), ctr.shape[-1],
+        _pf(ws[0][0]), ws[0][0].shape[1], _pf(ws[0][1]), len(ws[0][1]), _pf(ws[1][0]), ws[1][0].shape[1], _pf(ws[1][1]),
+        len(ws[1][1]), _pf(ws[2][0]), ws[2][0].shape[1], _pf(ws[2][1]), len(ws[2][1]), _pf(out), out.shape[-1], col0)
+    assert rc == 0
+    return out
 
 
 def linear(a, w, shift=None, act=0, k=None, idx=None, ctr=None, cnt=None, pool=0, out=None, col0=0):

@@ -118,6 +118,22 @@ def test_compact_groups_structure(b, n, m, ns, smin):
     assert hdr[9] == (want_cls).sum()
 
 
+@pytest.mark.parametrize("smin,split", [(1, 1), (1, 4), (4, 4), (4, 0), (2, 8)])
+def test_compact_groups_equals_c_oracle(oracle_ops, smin, split):
+    """device lists == the sequential C restatement, word for word (live rows; the rest of the capacity is scratch)"""
+    from de6d_amd.ops import fused
+    rng = np.random.default_rng(17 + smin + split)
+    b, n, m, ns = 3, 777, 1500, 32
+    cnt, idx = padded_query(rng, b, n, m, ns)
+    cr = build_list(fused, cnt, idx, n, smin, split)
+    ohdr, op, oc = oracle_ops.compact_groups(cnt, idx, n, smin=smin, split=max(split, smin) if split else 0)
+    hdr = cr.hdr.cpu().numpy()
+    np.testing.assert_array_equal(hdr[:10], ohdr[:10])
+    live = int(hdr[0])
+    np.testing.assert_array_equal(cr.crow_p.cpu().numpy()[:live], op[:live])
+    np.testing.assert_array_equal(cr.crow_c.cpu().numpy()[:live], oc[:live])
+
+
 def make_layers(rng, ld, c_in, widths):
     dims = [ld] + list(widths)
     layers_np, layers_dev = [], []

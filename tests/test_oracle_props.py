@@ -134,3 +134,34 @@ def test_linear_matches_numpy(oracle_ops):
     g[..., :3] -= ctr[:, :, None, :]
     want = np.maximum(g @ w + s, 0).max(axis=2) * (cnt > 0)[..., None]
     np.testing.assert_allclose(got.reshape(2, 3, 7), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("smin,split", [(1, 1), (1, 4), (4, 4), (4, 0), (2, 2)])
+def test_compact_rows_equal_dense_rows(oracle_ops, smin, split):
+    """The claim behind de6d_amd/csrc/compact.hip, checked on the CPU alone: a ball query pads a ball of cnt < nsample
+    hits with repetitions of its first cnt hits (ball_query_gpu.cu:75-90,114-129), so the grouped MLP + max-pool over
+    the compact row list (first cnt slots, cut into power-of-two parts) equals the MLP over ALL nsample rows bit for
+    bit — on the indices the oracle's own dilated ball query produces."""
+    rng = np.random.default_rng(5 + smin + split)
+    b, n, m, ns, c_in = 2, 600, 300, 8, 5
+    xyz = rng.uniform(-2, 2, (b, n, 3)).astype(np.float32)
+    ctr = xyz[:, rng.choice(n, m, replace=False)].copy()
+    cnt, idx = oracle_ops.ball_query_dilated(0.25, 0.55, ns, xyz, ctr)
+    assert 0 < (cnt == 0).sum() and (cnt >= ns).sum() > 0 and (cnt % 4 != 0).sum() > 0
+    ld = (3 + c_in + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3] = xyz
+    rows[..., 3:3 + c_in] = rng.normal(size=(b, n, c_in))
+    widths, layers, kin = (12, 20, 24), [], ld
+    for cout in widths:
+        w = np.zeros((kin, cout), np.float32)
+        w[:, :] = rng.normal(size=(kin, cout)) / np.sqrt(kin)
+        layers.append((w, rng.normal(size=(cout,)).astype(np.float32)))
+        kin = cout
+    h = oracle_ops.linear(rows, layers[0][0], layers[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(h, layers[1][0], layers[1][1], 1)
+    dense = oracle_ops.linear(h, layers[2][0], layers[2][1], 1, cnt=cnt, pool=ns)
+    lists = oracle_ops.compact_groups(cnt, idx, n, smin=smin, split=max(split, smin) if split else 0)
+    assert lists[0][8] == np.minimum(cnt, ns).sum() and lists[0][0] < b * m * ns
+    compact = oracle_ops.mlp_chain3_compact(rows, lists, ctr, layers, np.zeros((b * m, widths[2]), np.float32))
+    np.testing.assert_array_equal(compact, dense)
