@@ -32,7 +32,7 @@ class LinearArgs(ctypes.Structure):
                 ("ctr", c_void_p), ("ldctr", c_int),
                 ("pool", c_int),
                 ("cnt", c_void_p),
-                ("hdr", c_void_p), ("crow_p", c_void_p), ("crow_c", c_void_p)]
+                ("hdr", c_void_p), ("crow_p", c_void_p), ("crow_c", c_void_p), ("ncols_pad", c_int)]
 
 
 _P = c_void_p
@@ -78,7 +78,7 @@ _SIGNATURES = {
                          _P, c_int, _P, c_int, _P, c_int, c_int, _P],
     "det6d_mlp_chain3_compact": [c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
                                  _P, c_int, _P, c_int, c_int, _P],
-    "det6d_compact_groups": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
+    "det6d_compact_groups": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],
     "det6d_vote_points": [c_int, _P, c_int, _P, c_int, c_float, c_float, c_float, _P, c_int, _P, _P],
     "det6d_decode_boxes": [c_int, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P, _P],

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void compact_count_kernel(int total, int ns, i
 __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, int m, int ns, int smin, int split, int nblk,
                                                             const int *__restrict__ cnt, const int *__restrict__ idx,
                                                             const int *__restrict__ table, int *__restrict__ hdr,
-                                                            int *__restrict__ crow_p, int *__restrict__ crow_c) {
+                                                            int *__restrict__ crow_p, int *__restrict__ crow_c,
+                                                            float *__restrict__ zero_y, int ldy, int col0, int width) {
   __shared__ int h_all[kClasses + 1], h_before[kClasses];
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
@@ -133,6 +134,15 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
   }
   const int i0 = blockIdx.x * 256, i = i0 + tid;
   const bool ok = i < total;
+  // the slice of the pooled buffer this group's last layer max-combines into (multi-part centres: atomic max) starts
+  // at zero: cleared here, one launch earlier than its first writer, instead of by a separate fill
+  if (zero_y) {
+    const int w4 = width >> 2, nrow = total - i0 < 256 ? total - i0 : 256;
+    for (int e = tid; e < nrow * w4; e += 256) {
+      const int r = e / w4, c = e - r * w4;
+      *reinterpret_cast<float4 *>(zero_y + (size_t)(i0 + r) * ldy + col0 + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   int rows = 0;
   const int mask = ok ? parts_of(cnt[i], ns, smin, split, &rows) : 0;
   int rank[kClasses];
@@ -157,12 +167,10 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
     const int rw = rows_s[ci];
     if (t < rw) {
       const int cg = i0 + ci;
-      int row = 0;
-#pragma unroll
-      for (int cc = 0; cc < kClasses; ++cc) {   // the part that holds slot t: parts in descending size
-        const int sz = 32 >> cc, off = rw & ~(2 * sz - 1);
-        if ((rw & sz) && t >= off && t < off + sz) row = r0_s[ci][cc] + (t - off);
-      }
+      // the part that holds slot t (parts in descending size): the highest bit in which t and rw differ is set in rw
+      // (t < rw), the bits above it agree, so t lies in the part of that size, which starts at those common bits
+      const int pbit = 31 - __builtin_clz(rw ^ t), sz = 1 << pbit;
+      const int row = r0_s[ci][5 - pbit] + (t - (rw & ~(2 * sz - 1)));
       int tag = cg;
       if (cnt[cg] <= 0) tag |= 0x40000000;          // empty ball: pooled value 0
       if (rw & (rw - 1)) tag |= 0x20000000;          // several parts: combine with an atomic max
@@ -181,17 +189,19 @@ DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
 DET6D_API int det6d_compact_hdr_ints(int total_centres) { return 16 + (kClasses + 1) * (det6d_divup(total_centres, 256) + 1); }
 
 DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx,
-                                   int *hdr, int *crow_p, int *crow_c, det6d_stream_t stream) {
+                                   int *hdr, int *crow_p, int *crow_c, float *zero_y, int ldy, int col0, int width,
+                                   det6d_stream_t stream) {
   if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
   if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
   if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
   if (split < 0 || (split & (split - 1)) || (split && split < smin)) return DET6D_EINVAL;
   if (split > ns) split = ns;
+  if (zero_y && ((ldy | col0 | width) & 3 || ((uintptr_t)zero_y & 15) || width <= 0 || col0 + width > ldy)) return DET6D_EINVAL;
   const int total = b * m;
   const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
   int *table = hdr + 16;   // per-block counts behind the 16 header words (det6d_compact_hdr_ints)
   hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, ns, smin, split, cnt, table);
   hipLaunchKernelGGL(compact_place_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split, nblk, cnt,
-                     idx, table, hdr, crow_p, crow_c);
+                     idx, table, hdr, crow_p, crow_c, zero_y, ldy, col0, width);
   return det6d_check_launch("det6d_compact_groups");
 }

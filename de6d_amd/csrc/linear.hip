@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         for (int e = 0; e < 16; ++e) {
           const int row = rbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
           if (cok && row < R) g.y[(size_t)row * g.ldy + g.col0 + col] = relu_act(acc[i][j][e] + sh, g.act);
+          else if (col < g.ncols_pad && row < R) g.y[(size_t)row * g.ldy + g.col0 + col] = 0.f;   // padding columns of the next layer's K
         }
       } else {
         // rows of a tile: (e&3) + 8*(e>>2) + 4*kh  -> 8-row bundle q = e>>2 spans both lane halves.
@@ -562,6 +563,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   if (!a || a->rows < 0 || a->k <= 0 || a->ncols <= 0 || !a->a || !a->w || !a->y) return DET6D_EINVAL;
   if ((a->lda & 3) || (a->ldw & 3) || ((uintptr_t)a->a & 15) || ((uintptr_t)a->w & 15)) return DET6D_EINVAL;
   if (a->k > a->lda || a->ncols > a->ldw) return DET6D_EINVAL;
+  if (a->ncols_pad && (a->ncols_pad < a->ncols || a->ncols_pad > a->ncols + 3 || a->col0 + a->ncols_pad > a->ldy || a->pool)) return DET6D_EINVAL;
   if (a->mode == DET6D_A_GROUPED) {
     if (!a->idx || !a->ctr || a->ns <= 0 || a->m <= 0 || a->n <= 0 || a->ldctr < 3) return DET6D_EINVAL;
     if (a->rows % (a->m * a->ns)) return DET6D_EINVAL;

@@ -93,8 +93,9 @@ COMPACT_SMALL_CLASSES = True
 COMPACT_SPLIT = int(os.environ.get('DET6D_COMPACT_SPLIT', '1'))   # the granule g (0: padding to the next power of two)
 
 
-def compact_groups(cnt, idx, n):
-    """cnt (B,m), idx (B,m,ns) from a ball query over n points per scene -> CompactRows"""
+def compact_groups(cnt, idx, n, zero=None):
+    """cnt (B,m), idx (B,m,ns) from a ball query over n points per scene -> CompactRows.
+    zero = (pooled (B*m, ld), col0, width): that slice of the pooled buffer is cleared by the same call"""
     L.require_cuda(cnt, idx)
     b, m, ns = idx.shape
     cap = int(L.lib().det6d_compact_rows_capacity(b * m, ns))
@@ -102,12 +103,13 @@ def compact_groups(cnt, idx, n):
     crow_p = torch.empty((cap,), dtype=torch.int32, device=idx.device)
     crow_c = torch.empty((cap,), dtype=torch.int32, device=idx.device)
     L.call("det6d_compact_groups", b, n, m, ns, min(COMPACT_SMIN, ns), max(COMPACT_SPLIT, min(COMPACT_SMIN, ns)) if COMPACT_SPLIT else 0, L.ptr(cnt), L.ptr(idx),
-           L.ptr(hdr), L.ptr(crow_p), L.ptr(crow_c), L.stream_ptr())
+           L.ptr(hdr), L.ptr(crow_p), L.ptr(crow_c), L.ptr(zero[0]) if zero else None, zero[0].shape[-1] if zero else 0,
+           zero[1] if zero else 0, zero[2] if zero else 0, L.stream_ptr())
     return CompactRows(hdr, crow_p, crow_c, cap, ns)
 
 
 def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None, cnt=None, pool=0, compact=None,
-           gather=False):
+           gather=False, ncols_pad=0):
     """out[..., col0:col0+ncols] = act(A' @ W + shift) with optional neighbour gather / max-pool.
 
     a:   (R, lda) rows, or (B, n, lda) point rows when `idx` (B, m, ns) is given
@@ -144,6 +146,7 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
     else:
         g.mode, g.rows = 0, a.numel() // a.shape[-1]
     g.pool = pool
+    g.ncols_pad = ncols_pad      # columns [ncols, ncols_pad) of `out` are zero-filled by the kernel
     g.cnt = cnt.data_ptr() if cnt is not None else None
     if LINEAR_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -11,6 +11,33 @@ from ...ops.pointnet2.pointnet2_batch import pointnet2_modules
 from ...ops_backend import fused
 
 
+_DUMMY_LAUNCHES = int(__import__('os').environ.get('DET6D_DUMMY_LAUNCHES', '0'))
+
+
+class _LazyCoords(list):
+    """point_coords_list: (B*M, 4) [batch index, x, y, z] tensors of the SA levels, built from the (B, M, 3) centres on
+    first access"""
+
+    def __init__(self, xyz_levels):
+        super().__init__([None] * len(xyz_levels))
+        self._xyz = list(xyz_levels)
+
+    def _get(self, i):
+        v = list.__getitem__(self, i)
+        if v is None:
+            v = fused.with_batch_index(self._xyz[i], 3)
+            list.__setitem__(self, i, v)
+        return v
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(len(self)))]
+        return self._get(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self)))
+
+
 class PointNet2FSMSG(nn.Module):
     def __init__(self, model_cfg, input_channels, **kwargs):
         super().__init__()
@@ -80,13 +107,19 @@ class PointNet2FSMSG(nn.Module):
         xyz = xyz.view(batch_size, n, 3)
 
         l_xyz, l_rows, l_scores = [xyz], [rows], [None]
+        if _DUMMY_LAUNCHES:      # experiment only (scripts/gpu_sweep.sh): what one more tiny launch per pass costs
+            _d = torch.empty((64,), dtype=torch.float32, device=points.device)
+            for _ in range(_DUMMY_LAUNCHES):
+                _d.zero_()
         for sa in self.SA_modules:
             nx, nr, ns = sa.forward_rows(l_xyz[-1], l_rows[-1], scores=l_scores[-1])
             l_xyz.append(nx)
             l_rows.append(nr)
             l_scores.append(ns)
 
-        batch_dict['point_coords_list'] = [self._with_batch_column(x) for x in l_xyz[1:]]
+        # [batch index, x, y, z] rows of every level: built on first access (a list subclass), the inference path reads
+        # none of them and every small launch costs ~4 us of a step with many passes in flight
+        batch_dict['point_coords_list'] = _LazyCoords(l_xyz[1:])
         batch_dict['point_scores_list'] = [None if s is None else s.reshape(-1, 1) for s in l_scores[1:]]
 
         if self.FP_modules is not None:
@@ -101,10 +134,11 @@ class PointNet2FSMSG(nn.Module):
             out_xyz = l_xyz[out_idx]
         else:
             c_out = self.num_point_features
-            point_features = l_rows[-1][:, :, 3:3 + c_out].contiguous()
+            last = l_rows[-1]
+            point_features = last.view(-1, last.shape[-1])[:, 3:3 + c_out]   # (B*M, C) strided view of the rows, no copy
             out_xyz = l_xyz[-1]
             batch_dict['_det6d_rows'] = (out_xyz, l_rows[-1])
-        batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
+        batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1]) if point_features.is_contiguous() else point_features
         batch_dict['point_coords'] = self._with_batch_column(out_xyz)
         batch_dict['point_scores'] = l_scores[-1]
         return batch_dict

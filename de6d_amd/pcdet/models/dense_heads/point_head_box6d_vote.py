@@ -118,10 +118,10 @@ class PointHeadBox6DVote(nn.Module):
         # SA layer around the votes, then the FC towers
         _, pooled, _ = self.SA_module.forward_rows(xyz, rows, new_xyz=vote_xyz)
         shared = run_chain(pooled.view(b * p, -1), f['shared'])
-        cls = run_chain(shared, f['cls'])
-        reg = run_chain(shared, f['reg'])
         ncls, ncode = f['cls'][-1][2], f['reg'][-1][2]
-        point_cls_preds = cls[:, :ncls].contiguous()
+        point_cls_preds = torch.empty((b * p, ncls), dtype=torch.float32, device=rows.device)
+        run_chain(shared, f['cls'], out=point_cls_preds)            # the last layer writes the unpadded (B*P, ncls) logits
+        reg = run_chain(shared, f['reg'])
         point_reg_preds = reg[:, :ncode].contiguous() if reg.shape[1] != ncode else reg
 
         vote_flat = vote_xyz.view(b * p, 3)
@@ -131,7 +131,7 @@ class PointHeadBox6DVote(nn.Module):
         batch_dict['batch_index'] = cand4[:, 0]
         batch_dict['point_candidate_coords'] = cand4
         batch_dict['point_vote_coords'] = fused.with_batch_index(vote_xyz, 3)
-        batch_dict['vote_offsets'] = off_clamped.view(b, p, 3).permute(0, 2, 1).contiguous()
+        batch_dict['vote_offsets'] = off_clamped.view(b, p, 3).permute(0, 2, 1)   # (B, 3, P) view, no copy
         batch_dict['point_cls_scores'] = fused.sigmoid_pow(point_cls_preds, 1.0)
         batch_dict['point_box_preds'] = boxes
         batch_dict['batch_cls_preds'] = point_cls_preds

@@ -92,9 +92,8 @@ def run_chain(x, layers, out=None, col0=0):
             fused.linear(x, w, shift, act, out, ncols=cout, col0=col0)
             return out
         y = torch.empty((x.numel() // x.shape[-1], w.shape[1]), dtype=torch.float32, device=x.device)
-        if w.shape[1] != cout:
-            y[:, cout:].zero_()  # padded columns feed the next layer's zero weight rows
-        fused.linear(x, w, shift, act, y, ncols=cout)
+        # padded columns feed the next layer's zero weight rows: the kernel writes them as zeros
+        fused.linear(x, w, shift, act, y, ncols=cout, ncols_pad=w.shape[1] if w.shape[1] != cout else 0)
         x = y
     return x
 
@@ -221,12 +220,9 @@ class _PointnetSAModuleFSBase(nn.Module):
             else:
                 new_xyz = fused.gather_centres(xyz, sample_idx)
         m = new_xyz.shape[1]
-        if COMPACT_ROWS and fused.COMPACT_SPLIT:   # parts of a centre are combined by an atomic max into a zeroed buffer
-            pooled = torch.zeros((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
-        else:
-            pooled = torch.empty((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
-            if pooled.shape[1] != f['pooled_width']:
-                pooled[:, f['pooled_width']:].zero_()
+        pooled = torch.empty((b * m, round4(f['pooled_width'])), dtype=torch.float32, device=rows.device)
+        if pooled.shape[1] != f['pooled_width']:
+            pooled[:, f['pooled_width']:].zero_()
         col = 0
         # neighbour search: shells [former, radius) when dilated, plain balls otherwise
         shells, former_radius = [], 0.0
@@ -248,7 +244,14 @@ class _PointnetSAModuleFSBase(nn.Module):
                 found.append((idx_cnt, idx))
         for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
             if COMPACT_ROWS and nsample in (4, 8, 16, 32):
-                cr = fused.compact_groups(idx_cnt, idx, n)
+                # parts of a centre are combined by an atomic max: the group's slice of `pooled` is cleared by the list builder
+                w_out = layers[-1][2]
+                if fused.COMPACT_SPLIT and (col | w_out | pooled.shape[1]) % 4 == 0:
+                    cr = fused.compact_groups(idx_cnt, idx, n, zero=(pooled, col, w_out))
+                else:
+                    if fused.COMPACT_SPLIT:
+                        pooled[:, col:col + w_out].zero_()
+                    cr = fused.compact_groups(idx_cnt, idx, n)
                 if fused.chain_compact_eligible(rows.shape[-1], layers):
                     fused.mlp_chain3_compact(rows, cr, new_xyz, layers, pooled, col)
                     col += layers[-1][2]
@@ -259,9 +262,7 @@ class _PointnetSAModuleFSBase(nn.Module):
                         tgt, kw = pooled, dict(ncols=cout, col0=col, cnt=idx_cnt, pool=-1)
                     else:
                         tgt = torch.empty((cr.capacity, w.shape[1]), dtype=torch.float32, device=rows.device)
-                        if w.shape[1] != cout:
-                            tgt[:, cout:].zero_()
-                        kw = dict(ncols=cout)
+                        kw = dict(ncols=cout, ncols_pad=w.shape[1] if w.shape[1] != cout else 0)
                     if li == 0:
                         fused.linear(rows, w, shift, act, tgt, ctr=new_xyz, compact=cr, gather=True, **kw)
                     else:
@@ -281,9 +282,7 @@ class _PointnetSAModuleFSBase(nn.Module):
                     tgt, kw = pooled, dict(ncols=cout, col0=col, cnt=idx_cnt, pool=nsample)
                 else:
                     tgt = torch.empty((b * m * nsample, w.shape[1]), dtype=torch.float32, device=rows.device)
-                    if w.shape[1] != cout:
-                        tgt[:, cout:].zero_()
-                    kw = dict(ncols=cout)
+                    kw = dict(ncols=cout, ncols_pad=w.shape[1] if w.shape[1] != cout else 0)
                 if li == 0:
                     fused.linear(rows, w, shift, act, tgt, idx=idx, ctr=new_xyz, **kw)
                 else:
@@ -298,7 +297,11 @@ class _PointnetSAModuleFSBase(nn.Module):
                 new_rows = torch.zeros((b, m, rows_ld(f['out_channels'])), dtype=torch.float32, device=rows.device)
                 new_rows[:, :, :3] = new_xyz
             run_chain(pooled, f['agg'], out=new_rows, col0=3)
-            if f['conf'] is not None:
+            if f['conf'] is not None and f['conf'][-1][2] == 1:   # the last layer writes the (B*M, 1) score column itself
+                new_scores = torch.empty((b * m, 1), dtype=torch.float32, device=rows.device)
+                run_chain(new_rows, f['conf'], out=new_scores)
+                new_scores = new_scores.view(b, m)
+            elif f['conf'] is not None:
                 new_scores = run_chain(new_rows, f['conf'])[:, 0].reshape(b, m).contiguous()
             return new_xyz, new_rows, new_scores
         return new_xyz, pooled.view(b, m, -1), None

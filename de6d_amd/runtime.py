@@ -187,10 +187,11 @@ class GraphedDet6D(object):
             bd = {'batch_size': batch_size, 'points': self.points}
             for module in model.module_list:
                 bd = module(bd)
-            out = fused.postprocess(bd['batch_cls_preds'].contiguous(), bd['batch_box_preds'].contiguous(),
-                                    batch_size, pp.SCORE_THRESH, nms.NMS_PRE_MAXSIZE, nms.NMS_POST_MAXSIZE,
-                                    nms.NMS_THRESH)
-            return bd, out
+            boxes, scores, labels, index, count = fused.postprocess(
+                bd['batch_cls_preds'].contiguous(), bd['batch_box_preds'].contiguous(), batch_size, pp.SCORE_THRESH,
+                nms.NMS_PRE_MAXSIZE, nms.NMS_POST_MAXSIZE, nms.NMS_THRESH)
+            # pred_labels are int64 in the reference (detector3d_template.py:239): converted once, inside the graph
+            return bd, (boxes, scores, labels.long(), index, count)
 
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(self.stream):
@@ -265,7 +266,7 @@ class GraphedDet6D(object):
         """pred_dicts of the last launch (views into the graph's static outputs)"""
         self.done.synchronize()
         return [{'pred_boxes': self.boxes[i, :k], 'pred_scores': self.scores[i, :k],
-                 'pred_labels': self.labels[i, :k].long()} for i, k in enumerate(self.count_host.tolist())]
+                 'pred_labels': self.labels[i, :k]} for i, k in enumerate(self.count_host.tolist())]
 
 
 class Det6DGroup(object):

@@ -326,6 +326,8 @@ typedef struct det6d_linear_args {
   const int *crow_p;       /* mode COMPACT: point row (scene * n + neighbour) of every compact row; n = B * n */
   const int *crow_c;       /* mode COMPACT / pool -1: centre (scene * m + j) of every compact row (bit 30: empty
                               ball, pooled value 0), -1 = padding */
+  int ncols_pad;           /* > ncols: columns [ncols, ncols_pad) of y are written as zeros (the padded width the next
+                              layer reads), so callers need no separate fill; 0 = leave them alone */
 } det6d_linear_args;
 int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
 
@@ -342,11 +344,13 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  * split = g > 0 (a power of two >= smin): a centre with more than g hits takes ceil(cnt / g) * g rows, cut along their
  * binary digits into parts of descending size (20 = 16 + 4), each a group of its class; consumers combine the parts'
  * maxima with an integer atomic max on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before
- * the pooled layer runs.  Centres with <= g hits stay one part of the next power of two >= max(cnt, smin). */
+ * the pooled layer runs.  Centres with <= g hits stay one part of the next power of two >= max(cnt, smin).
+ * zero_y != NULL: columns [col0, col0 + width) of the (B*m, ldy) pooled buffer are cleared by this call (all multiples
+ * of 4), which saves the separate fill. */
 int det6d_compact_rows_capacity(int total_centres, int ns);
 int det6d_compact_hdr_ints(int total_centres);   /* ints the hdr buffer must hold (16 header words + scratch) */
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,
-                         int *crow_p, int *crow_c, det6d_stream_t stream);
+                         int *crow_p, int *crow_c, float *zero_y, int ldy, int col0, int width, det6d_stream_t stream);
 
 /* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to
  *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)

@@ -528,6 +528,7 @@ typedef struct det6d_linear_args {
   int pool;
   const int *cnt;
   const int *hdr, *crow_p, *crow_c;   /* compact row lists (det6d_oracle_compact_groups) */
+  int ncols_pad;                      /* zero-filled padding columns (ignored here: numpy callers allocate zeros) */
 } det6d_linear_args;
 
 /* Compact row lists: plain sequential restatement of de6d_amd/csrc/compact.hip (this is a data structure of the
@@ -545,8 +546,12 @@ static int compact_rows_of(int cnt, int ns, int smin, int split) {
   return rows;
 }
 ORACLE_API int det6d_oracle_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt,
-                                           const int *idx, int *hdr, int *crow_p, int *crow_c) {
+                                           const int *idx, int *hdr, int *crow_p, int *crow_c, float *zero_y, int ldy,
+                                           int col0, int width) {
   const int total = b * m;
+  if (zero_y)
+    for (int i = 0; i < total; ++i)
+      for (int c = 0; c < width; ++c) zero_y[(size_t)i * ldy + col0 + c] = 0.f;
   if (split > ns) split = ns;
   int count[6] = {0, 0, 0, 0, 0, 0}, start[7], next[6], real = 0, unaligned = 0;
   for (int i = 0; i < total; ++i) {

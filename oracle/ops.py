@@ -227,7 +227,7 @@ class _LinearArgs(ctypes.Structure):
                 ("ctr", _fp), ("ldctr", _c_int),
                 ("pool", _c_int),
                 ("cnt", _ip),
-                ("hdr", _ip), ("crow_p", _ip), ("crow_c", _ip)]
+                ("hdr", _ip), ("crow_p", _ip), ("crow_c", _ip), ("ncols_pad", _c_int)]
 
 
 def compact_groups(cnt, idx, n, smin=1, split=1):
@@ -237,7 +237,8 @@ def compact_groups(cnt, idx, n, smin=1, split=1):
     cap = int(lib().det6d_oracle_compact_rows_capacity(b * m, ns))
     hdr = np.zeros(int(lib().det6d_oracle_compact_hdr_ints(b * m)), np.int32)
     crow_p, crow_c = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
-    rc = lib().det6d_oracle_compact_groups(b, n, m, ns, smin, split, _pi(cnt), _pi(idx), _pi(hdr), _pi(crow_p), _pi(crow_c))
+    rc = lib().det6d_oracle_compact_groups(b, n, m, ns, smin, split, _pi(cnt), _pi(idx), _pi(hdr), _pi(crow_p), _pi(crow_c),
+                                           None, 0, 0, 0)
     assert rc == 0
     return hdr, crow_p, crow_c
 

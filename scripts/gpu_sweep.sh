@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-t() { python scripts/gpu_whatif2.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('nofps', sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
-t; t --streams 12; t --streams 8
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print(sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
+t; t; t --streams 12; t --streams 20

@@ -22,5 +22,23 @@ def fake_fps(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None):
         ctl.add_sampler(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset); return
     r = _rec[(lo, hi, m, scores is None)]
     idx_out[:, idx_offset:idx_offset + m] = r.repeat(idx_out.shape[0] // r.shape[0], 1)
-fused.fps_fused = fake_fps
+mode = os.environ.get('WHATIF', 'nofps')
+if 'nofps' in mode:
+    fused.fps_fused = fake_fps
+else:
+    fused.fps_fused = _real
+if 'nolinear' in mode:      # GEMM family stubbed out (outputs keep whatever the buffers hold): what everything else costs
+    _orig = fused.L.call
+    def call(name, *args):
+        if name in ('det6d_linear', 'det6d_mlp_chain3', 'det6d_mlp_chain3_compact'):
+            return 0
+        return _orig(name, *args)
+    fused.L.call = call
+if 'nocompact' in mode:
+    _orig2 = fused.L.call
+    def call2(name, *args):
+        if name == 'det6d_compact_groups':
+            return 0
+        return _orig2(name, *args)
+    fused.L.call = call2
 bench.main()
