@@ -49,8 +49,20 @@ __device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split, in
 }
 
 // pass 1: parts per class (and information rows) of every block of 256 centres -> table[block][kClasses + 1]
-__global__ __launch_bounds__(256) void compact_count_kernel(int total, int ns, int smin, int split, const int *__restrict__ cnt,
-                                                            int *__restrict__ table) {
+// one radius group of a layer: both groups of an SA layer share total / n / m and go through ONE launch (grid.y)
+struct GroupArgs {
+  int ns, smin, split;
+  const int *cnt, *idx;
+  int *hdr, *crow_p, *crow_c;
+  int col0, width;
+};
+struct PairArgs { GroupArgs g[2]; };
+
+__global__ __launch_bounds__(256) void compact_count_kernel(int total, const PairArgs pa) {
+  const GroupArgs &ga = pa.g[blockIdx.y];
+  const int ns = ga.ns, smin = ga.smin, split = ga.split;
+  const int *__restrict__ cnt = ga.cnt;
+  int *__restrict__ table = ga.hdr + 16;
   __shared__ int acc[kClasses + 1];
   const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
   if (tid <= kClasses) acc[tid] = 0;
@@ -73,11 +85,16 @@ __global__ __launch_bounds__(256) void compact_count_kernel(int total, int ns, i
 
 // pass 2: one workgroup per block of 256 centres: region starts and the block's first row per class from the table,
 // then ordered placement (ballot ranks per class), one thread per (centre, slot) for the row writes
-__global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, int m, int ns, int smin, int split, int nblk,
-                                                            const int *__restrict__ cnt, const int *__restrict__ idx,
-                                                            const int *__restrict__ table, int *__restrict__ hdr,
-                                                            int *__restrict__ crow_p, int *__restrict__ crow_c,
-                                                            float *__restrict__ zero_y, int ldy, int col0, int width) {
+__global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, int m, int nblk, float *__restrict__ zero_y, int ldy,
+                                                            const PairArgs pa) {
+  const GroupArgs &ga = pa.g[blockIdx.y];
+  const int ns = ga.ns, smin = ga.smin, split = ga.split, col0 = ga.col0, width = ga.width;
+  const int *__restrict__ cnt = ga.cnt;
+  const int *__restrict__ idx = ga.idx;
+  int *__restrict__ hdr = ga.hdr;
+  const int *__restrict__ table = ga.hdr + 16;
+  int *__restrict__ crow_p = ga.crow_p;
+  int *__restrict__ crow_c = ga.crow_c;
   __shared__ int h_all[kClasses + 1], h_before[kClasses];
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
@@ -188,20 +205,53 @@ DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
 
 DET6D_API int det6d_compact_hdr_ints(int total_centres) { return 16 + (kClasses + 1) * (det6d_divup(total_centres, 256) + 1); }
 
+static int check_group(int ns, int smin, int *split, const int *cnt, const int *idx, const int *hdr, const int *crow_p,
+                       const int *crow_c) {
+  if (!cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
+  if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
+  if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
+  if (*split < 0 || (*split & (*split - 1)) || (*split && *split < smin)) return DET6D_EINVAL;
+  if (*split > ns) *split = ns;
+  return DET6D_OK;
+}
+
+static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa, float *zero_y, int ldy, hipStream_t stream) {
+  const int total = b * m;
+  const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, pa);
+  hipLaunchKernelGGL(compact_place_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, n, m, nblk, zero_y, ldy, pa);
+  return det6d_check_launch("det6d_compact_groups");
+}
+
 DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx,
                                    int *hdr, int *crow_p, int *crow_c, float *zero_y, int ldy, int col0, int width,
                                    det6d_stream_t stream) {
-  if (b < 0 || n <= 0 || m <= 0 || !cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
-  if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
-  if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
-  if (split < 0 || (split & (split - 1)) || (split && split < smin)) return DET6D_EINVAL;
-  if (split > ns) split = ns;
+  if (b < 0 || n <= 0 || m <= 0) return DET6D_EINVAL;
+  if (check_group(ns, smin, &split, cnt, idx, hdr, crow_p, crow_c)) return DET6D_EINVAL;
   if (zero_y && ((ldy | col0 | width) & 3 || ((uintptr_t)zero_y & 15) || width <= 0 || col0 + width > ldy)) return DET6D_EINVAL;
-  const int total = b * m;
-  const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
-  int *table = hdr + 16;   // per-block counts behind the 16 header words (det6d_compact_hdr_ints)
-  hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, ns, smin, split, cnt, table);
-  hipLaunchKernelGGL(compact_place_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, total, n, m, ns, smin, split, nblk, cnt,
-                     idx, table, hdr, crow_p, crow_c, zero_y, ldy, col0, width);
-  return det6d_check_launch("det6d_compact_groups");
+  PairArgs pa;
+  pa.g[0] = GroupArgs{ns, smin, split, cnt, idx, hdr, crow_p, crow_c, col0, width};
+  pa.g[1] = pa.g[0];
+  return launch_groups(b, n, m, 1, pa, zero_y, ldy, (hipStream_t)stream);
+}
+
+// both radius groups of an SA layer (same centres, their own nsample / counts / indices / lists) in one pair of launches
+DET6D_API int det6d_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
+                                        int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
+                                        const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
+                                        int width_b, float *zero_y, int ldy, det6d_stream_t stream) {
+  if (b < 0 || n <= 0 || m <= 0) return DET6D_EINVAL;
+  int sa = split, sb = split;
+  const int smin_a = smin < ns_a ? smin : ns_a, smin_b = smin < ns_b ? smin : ns_b;
+  if (sa && sa < smin_a) sa = smin_a;
+  if (sb && sb < smin_b) sb = smin_b;
+  if (check_group(ns_a, smin_a, &sa, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a)) return DET6D_EINVAL;
+  if (check_group(ns_b, smin_b, &sb, cnt_b, idx_b, hdr_b, crow_p_b, crow_c_b)) return DET6D_EINVAL;
+  if (zero_y && ((ldy | col0_a | width_a | col0_b | width_b) & 3 || ((uintptr_t)zero_y & 15) || width_a <= 0 || width_b <= 0 ||
+                 col0_a + width_a > ldy || col0_b + width_b > ldy))
+    return DET6D_EINVAL;
+  PairArgs pa;
+  pa.g[0] = GroupArgs{ns_a, smin_a, sa, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a, col0_a, width_a};
+  pa.g[1] = GroupArgs{ns_b, smin_b, sb, cnt_b, idx_b, hdr_b, crow_p_b, crow_c_b, col0_b, width_b};
+  return launch_groups(b, n, m, 2, pa, zero_y, ldy, (hipStream_t)stream);
 }

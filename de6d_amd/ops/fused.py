@@ -108,6 +108,25 @@ def compact_groups(cnt, idx, n, zero=None):
     return CompactRows(hdr, crow_p, crow_c, cap, ns)
 
 
+def _alloc_lists(b, m, ns, device):
+    cap = int(L.lib().det6d_compact_rows_capacity(b * m, ns))
+    hdr = torch.empty((int(L.lib().det6d_compact_hdr_ints(b * m)),), dtype=torch.int32, device=device)
+    return CompactRows(hdr, torch.empty((cap,), dtype=torch.int32, device=device),
+                       torch.empty((cap,), dtype=torch.int32, device=device), cap, ns)
+
+
+def compact_groups_pair(found, n, pooled, cols):
+    """both radius groups of an SA layer: found = [(cnt, idx)] x 2, cols = [(col0, width)] x 2 of `pooled` (cleared)"""
+    (ca, ia), (cb, ib) = found
+    L.require_cuda(ca, ia, cb, ib, pooled)
+    b, m, _ = ia.shape
+    la, lb = _alloc_lists(b, m, ia.shape[2], ia.device), _alloc_lists(b, m, ib.shape[2], ib.device)
+    L.call("det6d_compact_groups_pair", b, n, m, COMPACT_SMIN, COMPACT_SPLIT, ia.shape[2], L.ptr(ca), L.ptr(ia), L.ptr(la.hdr),
+           L.ptr(la.crow_p), L.ptr(la.crow_c), cols[0][0], cols[0][1], ib.shape[2], L.ptr(cb), L.ptr(ib), L.ptr(lb.hdr),
+           L.ptr(lb.crow_p), L.ptr(lb.crow_c), cols[1][0], cols[1][1], L.ptr(pooled), pooled.shape[-1], L.stream_ptr())
+    return [la, lb]
+
+
 def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None, cnt=None, pool=0, compact=None,
            gather=False, ncols_pad=0):
     """out[..., col0:col0+ncols] = act(A' @ W + shift) with optional neighbour gather / max-pool.

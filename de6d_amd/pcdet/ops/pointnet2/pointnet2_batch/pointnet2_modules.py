@@ -242,11 +242,19 @@ class _PointnetSAModuleFSBase(nn.Module):
                 else:
                     pn2.ball_query_cnt_wrapper(b, n, m, rout, nsample, new_xyz, xyz, idx_cnt, idx)
                 found.append((idx_cnt, idx))
-        for (idx_cnt, idx), nsample, layers in zip(found, self.nsamples, f['groups']):
+        lists = [None] * len(found)
+        widths = [layers[-1][2] for layers in f['groups']]
+        if (COMPACT_ROWS and fused.COMPACT_SPLIT and len(found) == 2 and all(ns in (4, 8, 16, 32) for ns in self.nsamples)
+                and (widths[0] | widths[1] | pooled.shape[1]) % 4 == 0):
+            # both groups' lists in one pair of launches; their slices of `pooled` are cleared by the builder
+            lists = fused.compact_groups_pair(found, n, pooled, [(0, widths[0]), (widths[0], widths[1])])
+        for (idx_cnt, idx), nsample, layers, cr in zip(found, self.nsamples, f['groups'], lists):
             if COMPACT_ROWS and nsample in (4, 8, 16, 32):
                 # parts of a centre are combined by an atomic max: the group's slice of `pooled` is cleared by the list builder
                 w_out = layers[-1][2]
-                if fused.COMPACT_SPLIT and (col | w_out | pooled.shape[1]) % 4 == 0:
+                if cr is not None:
+                    pass
+                elif fused.COMPACT_SPLIT and (col | w_out | pooled.shape[1]) % 4 == 0:
                     cr = fused.compact_groups(idx_cnt, idx, n, zero=(pooled, col, w_out))
                 else:
                     if fused.COMPACT_SPLIT:

@@ -352,6 +352,12 @@ int det6d_compact_hdr_ints(int total_centres);   /* ints the hdr buffer must hol
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,
                          int *crow_p, int *crow_c, float *zero_y, int ldy, int col0, int width, det6d_stream_t stream);
 
+/* det6d_compact_groups for both radius groups (a, b) of one SA layer in one pair of launches */
+int det6d_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
+                              int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
+                              const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
+                              int width_b, float *zero_y, int ldy, det6d_stream_t stream);
+
 /* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to
  *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)
  * but the (rows x c1), (rows x c2) intermediates never leave the CU (csrc/mlp_chain.hip).  Supported shapes:

@@ -590,6 +590,18 @@ ORACLE_API int det6d_oracle_compact_groups(int b, int n, int m, int ns, int smin
   return 0;
 }
 
+ORACLE_API int det6d_oracle_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a,
+                                                const int *idx_a, int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a,
+                                                int width_a, int ns_b, const int *cnt_b, const int *idx_b, int *hdr_b,
+                                                int *crow_p_b, int *crow_c_b, int col0_b, int width_b, float *zero_y,
+                                                int ldy) {
+  const int sm_a = smin < ns_a ? smin : ns_a, sm_b = smin < ns_b ? smin : ns_b;
+  det6d_oracle_compact_groups(b, n, m, ns_a, sm_a, split && split < sm_a ? sm_a : split, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a,
+                              zero_y, ldy, col0_a, width_a);
+  return det6d_oracle_compact_groups(b, n, m, ns_b, sm_b, split && split < sm_b ? sm_b : split, cnt_b, idx_b, hdr_b, crow_p_b,
+                                     crow_c_b, zero_y, ldy, col0_b, width_b);
+}
+
 /* det6d_linear over a compact row list: rows = hdr[0]; mode 2 gathers through crow_p / crow_c; pool = -1 takes the
  * maximum over the rows of every centre (empty balls -> 0): a centre in ONE part overwrites y, a centre cut into
  * several parts is max-combined with what y holds (the caller zeroes it), like the kernels' atomic max. */
