@@ -136,30 +136,51 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
                          'Tr_velo2cam': np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)})
     meta = {'calib': [calib] * batch, 'image_shape': np.tile(np.array([[375, 1242]], np.int32), (batch, 1)),
             'frame_id': ['%06d' % i for i in range(batch)]}
-    runners = [GraphedDet6D(model, batch, n) for _ in range(depth)]
-    scratch = [(torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
-                torch.empty((batch,), dtype=torch.int32, device='cuda')) for _ in range(depth)]
+    # the same two-stage pipeline as the headline run (main()): stage 1 of a group = the input producer + pack + first
+    # sampler of its passes on a sampler stream, issued `prefetch` groups ahead; stage 2 = the rest of every pass
+    k, n_main, prefetch = 4, 16, 4
+    mains = [torch.cuda.Stream() for _ in range(n_main)]
+    samp = [torch.cuda.Stream() for _ in range(6)]
+    n_groups = n_main // k + prefetch
+    groups = [Det6DGroup(model, batch, n, k, samp[g % len(samp)], main_streams=[mains[(g * k + j) % n_main] for j in range(k)])
+              for g in range(n_groups)]
+    scratch = {}
+    for grp in groups:
+        for r in grp.runners:
+            scratch[id(r)] = (torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
+                              torch.empty((batch,), dtype=torch.int32, device='cuda'))
+    seed = [0]
 
-    def run(k):
+    def produce(r):
+        ws, cnt = scratch[id(r)]
+        seed[0] += 1
+        F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n, seed=seed[0], out=r.points, workspace=ws, n_in=cnt)
+
+    def run(steps_):
+        ngl = (steps_ + k - 1) // k
         inflight, n_annos = [], 0
-        for i in range(k):
-            rn, (ws, cnt) = runners[i % depth], scratch[i % depth]
-            if len(inflight) >= depth:
-                n_annos += len(KittiDataset.generate_prediction_dicts(meta, inflight.pop(0).finalize(), cfg.CLASS_NAMES))
-            with torch.cuda.stream(rn.stream):
-                F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n, seed=i, out=rn.points, workspace=ws, n_in=cnt)
-            inflight.append(rn.launch())
-        for rn in inflight:
-            n_annos += len(KittiDataset.generate_prediction_dicts(meta, rn.finalize(), cfg.CLASS_NAMES))
+        for g in range(min(prefetch, ngl)):
+            groups[g % n_groups].launch_front(produce)
+        for g in range(ngl):
+            if len(inflight) >= n_groups - prefetch:
+                for r in inflight.pop(0):
+                    n_annos += len(KittiDataset.generate_prediction_dicts(meta, r.finalize(), cfg.CLASS_NAMES))
+            if g + prefetch < ngl:
+                groups[(g + prefetch) % n_groups].launch_front(produce)
+            inflight.append(groups[g % n_groups].launch_rest())
+        for grp in inflight:
+            for r in grp:
+                n_annos += len(KittiDataset.generate_prediction_dicts(meta, r.finalize(), cfg.CLASS_NAMES))
         return n_annos
 
+    depth = n_main
     run(depth * 2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frames = run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"scenes_per_s": round(frames / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3), "batches_in_flight": depth,
+    return {"scenes_per_s": round(frames / dt, 1), "ms_per_batch": round(dt / ((steps + k - 1) // k * k) * 1e3, 3), "batches_in_flight": depth,
             "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
 
 

@@ -224,7 +224,9 @@ class GraphedDet6D(object):
         """segment 0 (everything before the first sampler) on the CURRENT stream (the group's sampler stream), once
         the pass's previous launch has finished with the buffers"""
         torch.cuda.current_stream().wait_event(self.done)
-        if points is not None and points.data_ptr() != self.points.data_ptr():
+        if callable(points):          # an input producer filling self.points on the current stream (bench.py pipeline leg)
+            points(self)
+        elif points is not None and points.data_ptr() != self.points.data_ptr():
             self.points.copy_(points, non_blocking=True)
         self.segments[0][0].replay()
 
