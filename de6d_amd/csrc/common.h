@@ -109,11 +109,12 @@ __device__ __forceinline__ void d6_sampler_priority() {
 // Dynamic LDS a sampler launch asks for ON TOP of its static use so that no workgroup that needs more than a few
 // KB of LDS (every GEMM-family kernel) becomes co-resident with it: beside fp32-MFMA waves the sampler's dependent
 // vector-ALU chain runs 5-6x slower (each instruction queues behind a 64-cycle MFMA; scripts/gpu_fps_interf.py:
-// 3.6 -> 16-20 ms for the SA1 sampler), which keeps half the chip's CUs hosting samplers.  DET6D_FPS_LDS_HOG=0
-// turns the reservation off.
+// 3.4 -> 6.5 ms in-kernel for the SA1 sampler).  Measured in the two-stage pipeline the co-resident GEMM waves are
+// still a net gain (9640 scenes/s without the reservation, 9235 with 8 KB left to others, 9670 with 40 KB), so the
+// reservation is OFF by default; DET6D_FPS_LDS_HOG=<KB left to other workgroups> turns it on.
 template <typename KernelT>
 static inline unsigned det6d_sampler_lds_hog(KernelT kernel, unsigned static_bytes) {
-  static const int keep_kb = getenv("DET6D_FPS_LDS_HOG") ? atoi(getenv("DET6D_FPS_LDS_HOG")) : 8;   // LDS left to others (KB); 0 = no reservation
+  static const int keep_kb = getenv("DET6D_FPS_LDS_HOG") ? atoi(getenv("DET6D_FPS_LDS_HOG")) : 0;   // LDS left to others (KB); 0 = no reservation
   if (keep_kb <= 0) return 0u;
   const unsigned total = 160u * 1024u, keep = (unsigned)keep_kb * 1024u;
   if (static_bytes + keep >= total) return 0u;
