@@ -581,7 +581,12 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   if (a->hdr && (a->rows & 127)) return DET6D_EINVAL;   // capacity of a compact row space (det6d_compact_rows_capacity)
   if (a->rows == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int gm = det6d_divup(a->rows, 128);
+  // tile choice by the EXPECTED live rows: a compact list is sized for the dense row space (capacity) but holds a
+  // fraction of it (DET6D_COMPACT_ROWS_EST = expected capacity / live ratio; the grid still covers the capacity)
+  static const int rows_est_div = getenv("DET6D_COMPACT_ROWS_EST") ? atoi(getenv("DET6D_COMPACT_ROWS_EST")) : 1;
+  const int rows_est = a->hdr && rows_est_div > 1 ? a->rows / rows_est_div : a->rows;
+  const int gm = det6d_divup(rows_est, 128);
+  const int gm_cap = det6d_divup(a->rows, 128);
   // the buffer-load fast path addresses A and W with 32-bit byte offsets
   const size_t a_rows = a->mode == DET6D_A_GROUPED ? (size_t)(a->rows / (a->m * a->ns)) * a->n
                         : a->mode == DET6D_A_COMPACT ? (size_t)a->n : (size_t)a->rows;
@@ -594,16 +599,16 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
         hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 0>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                            dim3(256), 0, s, *a);
       else if (a->ncols <= 512 && a->k <= 256)
-        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm_cap * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
       else
-        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, 0>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, 0>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     } else if (a->ncols > 32) {
       if (gm < 128)
         hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 0>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
       else
-        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 0>), dim3(gm_cap), dim3(256), 0, s, *a);
     } else {
-      hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1, 16, 1, 0>), dim3(gm), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1, 16, 1, 0>), dim3(gm_cap), dim3(256), 0, s, *a);
     }
     return det6d_check_launch("det6d_linear");
   }
@@ -629,22 +634,22 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
       // 128x64 tiles (5 waves/SIMD) used to win 2-7 % on short K loops; with the vector-ALU-free main loop
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
       // off by default (DET6D_LINEAR_K64MAX = largest K that still takes it)
-      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm_cap * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
     else if (nbuf2)
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else if (bk32 && a->k >= bk32)
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {
     if (gm < 128 && fast64)
       hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 2>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else if (gm < 128)
       hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64)), dim3(256), 0, s, *a);
     else
-      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm), dim3(256), 0, s, *a);
+      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm_cap), dim3(256), 0, s, *a);
   } else {
-    hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1>), dim3(gm), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 1, 1>), dim3(gm_cap), dim3(256), 0, s, *a);
   }
   return det6d_check_launch("det6d_linear");
 }
