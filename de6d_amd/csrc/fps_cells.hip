@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   __shared__ int slot_k[2][NW];
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
-  d6_sampler_priority();
+  if (dbg == 9) d6_sampler_priority();   // raised wave priority measured 1 % SLOWER in the pipeline (9668 vs 9750 scenes/s): DET6D_FPS_DBG=9 turns it on
   xyz += (size_t)blockIdx.x * xyz_bstride;
   perm += (size_t)blockIdx.x * n;
   idxs += (size_t)blockIdx.x * idx_bstride;
