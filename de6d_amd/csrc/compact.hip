@@ -178,20 +178,19 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
     r0_s[tid][cc] = base[cc] + (before + rank[cc]) * (32 >> cc);
   }
   __syncthreads();
-  const int lg = 31 - __builtin_clz(ns);
-  for (int e = tid; e < 256 * ns; e += 256) {
-    const int ci = e >> lg, t = e & (ns - 1);
-    const int rw = rows_s[ci];
-    if (t < rw) {
-      const int cg = i0 + ci;
-      // the part that holds slot t (parts in descending size): the highest bit in which t and rw differ is set in rw
-      // (t < rw), the bits above it agree, so t lies in the part of that size, which starts at those common bits
-      const int pbit = 31 - __builtin_clz(rw ^ t), sz = 1 << pbit;
-      const int row = r0_s[ci][5 - pbit] + (t - (rw & ~(2 * sz - 1)));
-      int tag = cg;
-      if (cnt[cg] <= 0) tag |= 0x40000000;          // empty ball: pooled value 0
-      if (rw & (rw - 1)) tag |= 0x20000000;          // several parts: combine with an atomic max
-      crow_p[row] = (cg / m) * n + idx[(size_t)cg * ns + t];
+  // rows of this thread's own centre (1-5 on FPS-sampled clouds, against nsample = 16 / 32 slots): the part that holds
+  // slot t (parts in descending size) is found from the highest bit in which t and `rows` differ — it is set in `rows`
+  // (t < rows) and the bits above it agree, so t lies in the part of that size, which starts at those common bits
+  if (ok) {
+    int tag = i;
+    if (cnt[i] <= 0) tag |= 0x40000000;            // empty ball: pooled value 0
+    if (rows & (rows - 1)) tag |= 0x20000000;      // several parts: combine with an atomic max
+    const int prow = (i / m) * n;
+    const int *src = idx + (size_t)i * ns;
+    for (int t = 0; t < rows; ++t) {
+      const int pbit = 31 - __builtin_clz(rows ^ t), sz = 1 << pbit;
+      const int row = r0_s[tid][5 - pbit] + (t - (rows & ~(2 * sz - 1)));
+      crow_p[row] = prow + src[t];
       crow_c[row] = tag;
     }
   }
