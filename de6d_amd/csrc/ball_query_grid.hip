@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
     int *__restrict__ idx_a, int *__restrict__ cnt_b, int *__restrict__ idx_b) {
   extern __shared__ unsigned bitmaps[];            // [kQueryWaves][2][words]
   __shared__ int hits[kQueryWaves][2][kMaxNs];
+  __shared__ int lists[kQueryWaves][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bs = blockIdx.y;
   unsigned *bm_a = bitmaps + (size_t)(wave * 2 + 0) * words;
@@ -162,9 +163,58 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
     const int y0 = max(cy - 1, 0), y1 = min(cy + 1, h.ny - 1);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    // 1. mark hits (order-free)
+    // 1a. short lists: the hits of a centre (a handful on FPS-sampled clouds) are appended, unordered, to one 64-entry
+    //     list per shell through ballots; each hit then finds its rank by index among the others (one lane per hit,
+    //     an LDS broadcast read per other hit) — the "first nsample by ascending index" contract without touching the
+    //     N-bit bitmaps.  A shell with more than 64 hits falls back to the bitmap path below for this centre.
+    int na = 0, nb = 0;
+    int *la = lists[wave][0], *lb = lists[wave][1];
     for (int y = y0; y <= y1; ++y) {
       const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];   // x-contiguous cells: one range
+      for (int t0 = beg; t0 < end; t0 += 64) {
+        const int t = t0 + lane;
+        bool ha = false, hb = false;
+        int k = 0;
+        if (t < end) {
+          k = si[t];
+          const float x = p[(size_t)k * 3 + 0], yy = p[(size_t)k * 3 + 1], z = p[(size_t)k * 3 + 2];
+          const float d2 = d6_sqdist(qx - x, qy - yy, qz - z);
+          ha = d2 >= rin2_a && d2 < rout2_a;
+          hb = d2 >= rin2_b && d2 < rout2_b;
+        }
+        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ha) { const int pos = na + __popcll(ma & below); if (pos < 64) la[pos] = k; }
+        if (hb) { const int pos = nb + __popcll(mb & below); if (pos < 64) lb[pos] = k; }
+        na += __popcll(ma);
+        nb += __popcll(mb);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (na <= 64 && nb <= 64) {
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        const int *lst = sh == 0 ? la : lb;
+        const int total = sh == 0 ? na : nb;
+        const int ns = sh == 0 ? ns_a : ns_b;
+        int *hbuf = hits[wave][sh];
+        const int mine = lane < total ? lst[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < total; ++j) rank += lst[j] < mine;      // point indices are distinct
+        if (lane < total && rank < ns) hbuf[rank] = mine;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(total, ns);
+        int *out = (sh == 0 ? idx_a : idx_b) + ((size_t)bs * m + ci) * ns;
+        if (lane == 0) (sh == 0 ? cnt_a : cnt_b)[(size_t)bs * m + ci] = cnt;
+        for (int l = lane; l < ns; l += 64) out[l] = cnt > 0 ? hbuf[l % cnt] : 0;
+      }
+      continue;
+    }
+    // 1b. (more than 64 hits in a shell) mark hits in the bitmaps (order-free)
+    for (int y = y0; y <= y1; ++y) {
+      const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];
       for (int t = beg + lane; t < end; t += 64) {
         const int k = si[t];
         const float x = p[(size_t)k * 3 + 0], yy = p[(size_t)k * 3 + 1], z = p[(size_t)k * 3 + 2];
