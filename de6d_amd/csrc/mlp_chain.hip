@@ -25,6 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kChainWaves = 4;
+constexpr int kPackTiles = 1;    // compact lists: tiles per wave before another workgroup is used (1: 9970, 2: 9910, 4: 9780 scenes/s)
 constexpr int kTS = 33;       // row stride of the wave-private [channel][row] tiles
 constexpr int kMaxK1 = 8;     // input row width (x,y,z,features + pad)
 constexpr int kMaxC = 32;     // hidden widths
@@ -251,8 +252,19 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
   constexpr int S2 = C1 / 2, S3 = C2 / 2, NT3 = C3 / 32;
   const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int n_waves = (gridDim.x * blockDim.x) >> 6;
+  int pk_end = 0;
+  if (COMPACT) {   // tiles of a compact list packed onto few waves (>= kPackTiles each): fewer weight-fragment loads, fewer CUs held
+    const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32;
+    int T = (live + n_waves - 1) / n_waves;
+    if (T < kPackTiles) T = kPackTiles;
+    const int base = blockIdx.x * wpw * T;
+    if (base >= live) return;
+    wave_global = base + (threadIdx.x >> 6);
+    n_waves = wpw;
+    pk_end = base + wpw * T < live ? base + wpw * T : live;
+  }
 
   // weight fragments: lane (channel / column = l31, k = 2s + kh); one more step per transposed layer for the shift
   float wf1[S1 + 1], wf2[S2 + 1], wf3[NT3][S3];
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
 
   int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
   if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
-  const int ntiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
+  const int ntiles = COMPACT ? pk_end : g.rows / 32;   // end of this wave's tile range
   const int *nb_idx = COMPACT ? g.crow_p : g.idx;   // per-row neighbour: point index inside the scene / global point row
   // the tile index is wave-uniform: kept in SGPRs so that the batch index (a division by m) is scalar work
   int tile = __builtin_amdgcn_readfirstlane(wave_global);
@@ -443,8 +455,20 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   float *W2 = W1 + (K1 + 2) * C1;           // (C1 + 2) x C2
   float *W3 = W2 + (C1 + 2) * C2;           // C2 x C3
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-  // compact lists: the grid is sized for the capacity; workgroups without a live tile leave before staging 66-92 KB of weights
-  if (COMPACT && (int)(blockIdx.x * (blockDim.x >> 6)) >= g.hdr[0] / 32) return;
+  // compact lists: the grid is sized for the capacity but the list holds a fraction of it.  Its tiles are PACKED onto few
+  // workgroups — at least kPackTiles tiles per wave, workgroup w owns tiles [w * 8T, (w + 1) * 8T) — so that the 66-92 KB
+  // of weights are staged by ~35 workgroups instead of 256 (SA2, batch 8); the others leave before staging.
+  int pk_stride = 0, pk_first = 0, pk_end = 0;
+  if (COMPACT) {
+    const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32, waves = gridDim.x * wpw;
+    int T = (live + waves - 1) / waves;
+    if (T < kPackTiles) T = kPackTiles;
+    const int base = blockIdx.x * wpw * T;
+    if (base >= live) return;
+    pk_stride = wpw;
+    pk_first = base + (tid >> 6);
+    pk_end = base + wpw * T < live ? base + wpw * T : live;
+  }
   // staging with 16-byte loads (all leading dimensions and widths are multiples of 4)
   auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols) {
     const int c4 = cols / 4;
@@ -465,10 +489,11 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   __syncthreads();
 
   const float one_k0 = kh == 0 ? 1.f : 0.f;
-  const int wave_global = (blockIdx.x * blockDim.x + tid) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int wave_global = COMPACT ? pk_first : (int)((blockIdx.x * blockDim.x + tid) >> 6);
+  const int n_waves = COMPACT ? pk_stride : (int)((gridDim.x * blockDim.x) >> 6);   // tile stride of this wave
   int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
   if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
-  const int ntiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
+  const int ntiles = COMPACT ? pk_end : g.rows / 32;                                 // end of this wave's tile range
   int tile = __builtin_amdgcn_readfirstlane(wave_global);
   if (tile >= ntiles) return;
 

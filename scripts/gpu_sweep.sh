@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "ball or model or tiny or grid or waymo or class or sloped" 2>&1 | tail -3
-t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print(sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
+for T in 1 2; do
+sed -i "s/constexpr int kPackTiles = [0-9]*;/constexpr int kPackTiles = $T;/" de6d_amd/csrc/mlp_chain.hip
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2
+t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('T', sys.argv[1], d['value'], d['ms_per_step'])" $T; }
 t; t
-bash scripts/gpu_launch_list.sh > /dev/null 2>&1; grep -n "bq_grid" gpurun_out/launch_list/one_pass.txt | cut -c1-100
+done
