@@ -3,10 +3,13 @@
 
 One "step" = one full pass (PointNet2FSMSG backbone -> PointHeadBox6DVote -> rotated NMS
 post-processing, detections sliced per scene) over one batch of 8 synthetic 16384-point
-KITTI-like scenes already resident in HBM (BASELINE.json configs[1]).  Steps are issued
-round-robin on a few HIP streams so that the latency-bound FPS rounds of one batch (one
-workgroup per scene) overlap the MFMA GEMMs of the others; every step is finalised (its
-per-scene detections materialised) inside the timed region.
+KITTI-like scenes already resident in HBM (BASELINE.json configs[1]).  The passes run through a
+two-stage software pipeline (de6d_amd/runtime.py: Det6DGroup): stage 1 = pack + farthest point
+sampling of the input clouds of a GROUP of 4 passes, one launch on a sampler stream, issued 4
+groups ahead; stage 2 = the rest of every pass (captured hipGraph segments) on 16 main streams,
+so the latency-bound sampling rounds (one workgroup per scene) overlap the MFMA GEMMs of other
+passes.  Every pass still processes its own batch of 8 scenes and every step is finalised (its
+per-scene detections materialised on the host side) inside the timed region.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -23,8 +26,9 @@ import time
 
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, the
 # passes kept in flight serialise 4-wide.  Measured on MI355X: early in the round (24 streams) 4 queues 2051
-# scenes/s, 8 -> 2039, 16 -> 2929, 32 -> 2482; with the final kernels and linear (fork-free) graphs 16 queues /
-# 15 streams 4372, 20 / 18 4465, 24 / 22 4549, 32 / 24 4434.  Must be set before the HIP runtime initialises.
+# scenes/s, 8 -> 2039, 16 -> 2929, 32 -> 2482; single-graph passes 16 queues / 15 streams 4372, 24 / 22 4549,
+# 32 / 24 4434; two-stage pipeline (16 main + 6 sampler streams) 24 queues 9680, 28 -> 7720, 32 -> 8140.
+# Must be set before the HIP runtime initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 
 import numpy as np  # noqa: E402
@@ -242,7 +246,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=16, help='passes in flight; keep it below GPU_MAX_HW_QUEUES - 1 (24 queues: 18 -> 4454, 20 -> 4500, 22 -> 4549, 23 -> 4434 scenes/s; 16 queues: 15 -> 4372)')
+    ap.add_argument('--streams', type=int, default=16, help='main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
     ap.add_argument('--prefetch', type=int, default=4, help='groups whose sampler stage is issued ahead of the GEMM stage')
     ap.add_argument('--sampler-streams', type=int, default=6)
     ap.add_argument('--group', type=int, default=4, help='passes whose first (input-only) sampler runs as one high-priority launch; 1 = every pass is a single captured graph')
