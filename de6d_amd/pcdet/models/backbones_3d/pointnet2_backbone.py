@@ -11,9 +11,6 @@ from ...ops.pointnet2.pointnet2_batch import pointnet2_modules
 from ...ops_backend import fused
 
 
-_DUMMY_LAUNCHES = int(__import__('os').environ.get('DET6D_DUMMY_LAUNCHES', '0'))
-
-
 class _LazyCoords(list):
     """point_coords_list: (B*M, 4) [batch index, x, y, z] tensors of the SA levels, built from the (B, M, 3) centres on
     first access"""
@@ -107,10 +104,6 @@ class PointNet2FSMSG(nn.Module):
         xyz = xyz.view(batch_size, n, 3)
 
         l_xyz, l_rows, l_scores = [xyz], [rows], [None]
-        if _DUMMY_LAUNCHES:      # experiment only (scripts/gpu_sweep.sh): what one more tiny launch per pass costs
-            _d = torch.empty((64,), dtype=torch.float32, device=points.device)
-            for _ in range(_DUMMY_LAUNCHES):
-                _d.zero_()
         for sa in self.SA_modules:
             nx, nr, ns = sa.forward_rows(l_xyz[-1], l_rows[-1], scores=l_scores[-1])
             l_xyz.append(nx)
