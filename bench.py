@@ -188,6 +188,45 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
             "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
 
 
+def family_saturated(replay, n_streams=16, reps=8):
+    """wall time of the GEMM-family launches of one pass re-issued concurrently on n_streams streams.  Every stream
+    writes its own copies of the outputs (and reads its own copies of the intermediates), like passes in flight do;
+    weights, point rows and row lists are shared, as in the pipeline."""
+    if not replay:
+        return None
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    graphs, keep = [], []
+    torch.cuda.synchronize()
+    for si, st in enumerate(streams):   # every stream starts at another launch of the pass, as passes in flight do
+        own = {}
+        for _, out, _ in replay:
+            if out.data_ptr() not in own:
+                own[out.data_ptr()] = out.clone()
+        keep.append(own)
+
+        def ptr_of(t, own=own):
+            c = own.get(t.data_ptr())
+            return (c if c is not None else t).data_ptr()
+        g = torch.cuda.CUDAGraph()
+        rot = (si * len(replay)) // n_streams
+        with torch.cuda.graph(g, stream=st):
+            for issue, _, _ in replay[rot:] + replay[:rot]:
+                issue(ptr_of)
+        graphs.append(g)
+
+    def run(k):
+        for _ in range(k):
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(reps)
+    torch.cuda.synchronize()
+    return {"seconds": time.perf_counter() - t0, "passes": n_streams * reps, "streams": n_streams, "replays": reps}
+
+
 def linear_roofline(model, points, batch, flops_per_scene):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel + the register chain kernels: the
     SA / head MLP GEMMs) measured live with HIP events on the launch stream over one step.
@@ -198,12 +237,13 @@ def linear_roofline(model, points, batch, flops_per_scene):
       issued      = rows the kernels actually multiply (class padding to 4 / 8 / 16 / 32 and 128-row alignment on top),
       dense       = the reference's (centres x nsample) row space, SURVEY.md 8d's 22.583 GFLOP per scene.
     `achieved` prices the ALGORITHMIC flops: padding the kernels add for their own convenience earns nothing."""
-    fused.LINEAR_EVENTS = []
+    fused.LINEAR_EVENTS, fused.LINEAR_REPLAY = [], []
     with torch.no_grad():
         model({'batch_size': batch, 'points': points})
     torch.cuda.synchronize()
-    ev = fused.LINEAR_EVENTS
-    fused.LINEAR_EVENTS = None
+    ev, replay = fused.LINEAR_EVENTS, fused.LINEAR_REPLAY
+    fused.LINEAR_EVENTS = fused.LINEAR_REPLAY = None
+    saturated = family_saturated(replay)
     total_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
     issued = useful = 0.0
     fill = []
@@ -236,6 +276,15 @@ def linear_roofline(model, points, batch, flops_per_scene):
             "issued_tflops": round(issued / (total_ms * 1e-3) / 1e12, 2),
             "dense_equivalent_tflops": round(dense / (total_ms * 1e-3) / 1e12, 2),
             "compact_rows_centres_information_issued": groups,
+            # the same launches with the chip FULL: one pass's GEMM-family launches captured per stream and replayed
+            # concurrently on 16 streams, each starting at another launch of the pass and writing its own copies of the
+            # outputs, wall clock over 8 replays each.  `achieved` above times the launches one at a time on an idle chip.
+            "saturated": None if saturated is None else {
+                "tflops": round(useful * saturated["passes"] / saturated["seconds"] / 1e12, 2),
+                "frac": round(useful * saturated["passes"] / saturated["seconds"] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "issued_tflops": round(issued * saturated["passes"] / saturated["seconds"] / 1e12, 2),
+                "streams": saturated["streams"], "replays_per_stream": saturated["replays"],
+                "family_ms_per_pass": round(saturated["seconds"] / saturated["passes"] * 1e3, 4)},
             "kernel_ms_per_step": round(total_ms, 3)}
 
 

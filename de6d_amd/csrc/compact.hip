@@ -31,14 +31,16 @@ constexpr int kClasses = 6;
 //              class-4 group); the pooled value of the centre is the maximum over its parts, combined by an integer
 //              atomic max on the (non-negative, post-ReLU) outputs (bit 29 of crow_c marks such rows; the pooled
 //              buffer is zeroed first).  smin = 1, g = 4: singles and pairs are rows of their own, no atomics for them.
-__device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split, int *rows_out) {
+__device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split_tol, int *rows_out) {
   const int k = cnt < 1 ? 1 : (cnt > ns ? ns : cnt);
+  const int split = split_tol & 0xff, tol = split_tol >> 8;   // tol t > 0: one power-of-two part when it wastes <= 1/t of its rows
+  int p2 = smin;
+  while (p2 < k) p2 <<= 1;
   int rows;
-  if (split > 0 && k > split) {
+  if (split > 0 && k > split && !(tol > 0 && (p2 - k) * tol <= p2)) {
     rows = (k + split - 1) / split * split;
   } else {
-    rows = smin;
-    while (rows < k) rows <<= 1;
+    rows = p2;
   }
   *rows_out = rows;
   int mask = 0;
@@ -214,7 +216,11 @@ static int check_group(int ns, int smin, int *split, const int *cnt, const int *
   return DET6D_OK;
 }
 
-static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa, float *zero_y, int ldy, hipStream_t stream) {
+static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa_in, float *zero_y, int ldy, hipStream_t stream) {
+  // experiment knob: DET6D_COMPACT_TOL=t keeps a centre in ONE power-of-two part when that wastes <= 1/t of its rows
+  static const int tol = getenv("DET6D_COMPACT_TOL") ? atoi(getenv("DET6D_COMPACT_TOL")) : 0;
+  PairArgs pa = pa_in;
+  if (tol > 0) { pa.g[0].split |= tol << 8; pa.g[1].split |= tol << 8; }
   const int total = b * m;
   const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
   hipLaunchKernelGGL(compact_count_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, pa);

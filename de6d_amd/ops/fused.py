@@ -11,6 +11,9 @@ from .. import _lib as L
 
 #: when set to a list, linear() appends (start_event, end_event) recorded on the launch stream
 LINEAR_EVENTS = None
+#: when a list: every GEMM-family launch appends (re-issue closure, tensors it keeps alive) — bench.py replays one
+#: pass's launches concurrently on many streams to measure the family with the chip full
+LINEAR_REPLAY = None
 
 
 def pack_points(points, ld):
@@ -167,6 +170,12 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
     g.pool = pool
     g.ncols_pad = ncols_pad      # columns [ncols, ncols_pad) of `out` are zero-filled by the kernel
     g.cnt = cnt.data_ptr() if cnt is not None else None
+    if LINEAR_REPLAY is not None:
+        def reissue(ptr_of, g=g, a=a, out=out):     # ptr_of: tensor -> device pointer of the replaying stream's own copy
+            g2 = L.LinearArgs.from_buffer_copy(g)
+            g2.a, g2.y = ptr_of(a), ptr_of(out)
+            L.call("det6d_linear", ctypes.byref(g2), L.stream_ptr())
+        LINEAR_REPLAY.append((reissue, out, (g, a, w, shift, out, idx, ctr, cnt, compact)))
     if LINEAR_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -300,9 +309,14 @@ def mlp_chain3_compact(rows_pts, cr, ctr, layers, out, col0):
     if LINEAR_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    L.call("det6d_mlp_chain3_compact", cr.capacity, L.ptr(cr.hdr), L.ptr(cr.crow_p), L.ptr(cr.crow_c), L.ptr(rows_pts),
-           rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1], L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
-           L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, L.ptr(out), out.shape[-1], col0, L.stream_ptr())
+    def issue(ptr_of=None):
+        y = L.ptr(out) if ptr_of is None else ctypes.c_void_p(ptr_of(out))
+        L.call("det6d_mlp_chain3_compact", cr.capacity, L.ptr(cr.hdr), L.ptr(cr.crow_p), L.ptr(cr.crow_c), L.ptr(rows_pts),
+               rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1], L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
+               L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, y, out.shape[-1], col0, L.stream_ptr())
+    if LINEAR_REPLAY is not None:
+        LINEAR_REPLAY.append((issue, out, (rows_pts, cr, ctr, layers, out)))
+    issue()
     if ev is not None:
         ev[1].record()
         LINEAR_EVENTS.append((ev[0], ev[1], cr.hdr, 1, (rows_pts.shape[-1] * c1 + c1 * c2 + c2 * c3)))
