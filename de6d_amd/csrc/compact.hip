@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
   __shared__ int h_all[kClasses + 1], h_before[kClasses];
   __shared__ int wave_cnt[4][kClasses];
   __shared__ int start[kClasses + 1], base[kClasses];
-  __shared__ int r0_s[256][kClasses], rows_s[256];
+  __shared__ int r0_s[256][kClasses];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid <= kClasses) h_all[tid] = 0;
   if (tid < kClasses) h_before[tid] = 0;
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
     if (lane == 0) wave_cnt[wave][cc] = __popcll(mk);
   }
   __syncthreads();
-  rows_s[tid] = rows;
 #pragma unroll
   for (int cc = 0; cc < kClasses; ++cc) {
     int before = 0;

@@ -612,11 +612,16 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
     }
     return det6d_check_launch("det6d_linear");
   }
-  static const int force_k_max = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : 0;
+  // compact lists (a->hdr): launches of 7-43 k live rows; 128x64 tiles fill the idle chip better when such a launch runs
+  // alone (GEMM family 52 -> 56 TF stand-alone) and are neutral with 16 passes in flight (9930 vs 9920 scenes/s, family
+  // at saturation 90.6 vs 90.2 TF), so they are the default there; dense rows keep 128x128
+  static const int k64_env = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : -1;
+  static const int n64_env = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : -1;
+  const int force_k_max = k64_env >= 0 ? k64_env : (a->hdr ? 512 : 0);
   static const bool fast64 = getenv("DET6D_LINEAR_FAST64") ? atoi(getenv("DET6D_LINEAR_FAST64")) != 0 : false;
   static const bool nbuf2 = getenv("DET6D_LINEAR_NBUF2") != nullptr;   // double-buffered LDS tiles, one barrier per slab
   static const int bk32 = getenv("DET6D_LINEAR_BK32") ? atoi(getenv("DET6D_LINEAR_BK32")) : 0;   // K from which BK = 32 is used
-  static const int force_n_max = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : 512;
+  const int force_n_max = n64_env >= 0 ? n64_env : (a->hdr ? 1024 : 512);
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
     // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles.  These

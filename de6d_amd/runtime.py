@@ -90,7 +90,7 @@ def mlp_flops_per_scene(model, n_points):
 #: high-priority streams only FOUR hardware queues (scripts/gpu_prio_queues.py), so the first sampler — the one
 #: that depends on nothing but the input cloud — is cut out of the captured passes and launched ONCE for a group
 #: of passes on a high-priority stream (Det6DGroup); everything else replays as graph segments at normal priority.
-SAMPLER_GROUP = int(os.environ.get('DET6D_SAMPLER_GROUP', '4'))
+SAMPLER_GROUP = 4   # passes per group in bench.py (--group)
 
 
 class _SegmentCapture(object):
