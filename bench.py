@@ -188,7 +188,7 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
             "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
 
 
-def family_saturated(replay, n_streams=16, reps=8):
+def family_saturated(replay, n_streams=16, reps=24):
     """wall time of the GEMM-family launches of one pass re-issued concurrently on n_streams streams.  Every stream
     writes its own copies of the outputs (and reads its own copies of the intermediates), like passes in flight do;
     weights, point rows and row lists are shared, as in the pipeline."""
@@ -278,7 +278,7 @@ def linear_roofline(model, points, batch, flops_per_scene):
             "compact_rows_centres_information_issued": groups,
             # the same launches with the chip FULL: one pass's GEMM-family launches captured per stream and replayed
             # concurrently on 16 streams, each starting at another launch of the pass and writing its own copies of the
-            # outputs, wall clock over 8 replays each.  `achieved` above times the launches one at a time on an idle chip.
+            # outputs, wall clock over 24 replays each.  `achieved` above times the launches one at a time on an idle chip.
             "saturated": None if saturated is None else {
                 "tflops": round(useful * saturated["passes"] / saturated["seconds"] / 1e12, 2),
                 "frac": round(useful * saturated["passes"] / saturated["seconds"] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_compact_gpu.py tests/test_model_gpu.py -x -q -m gpu 2>&1 | tail -2
-t() { python bench.py --cpu-scenes 0 $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); r=d['roofline']; print('k64max', os.environ.get('DET6D_LINEAR_K64MAX'), d['value'], d['ms_per_step'], 'standalone', r['achieved'], r['frac'], 'saturated', r['saturated']['tflops'], r['saturated']['family_ms_per_pass'])" $*; }
-t; DET6D_LINEAR_K64MAX=0 t; t; DET6D_LINEAR_K64MAX=0 t
+t() { GPU_MAX_HW_QUEUES=$1 python bench.py --cpu-scenes 0 --no-roofline --streams $2 --group $3 --prefetch $4 --sampler-streams $5 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('queues', sys.argv[1], 'main', sys.argv[2], 'group', sys.argv[3], 'prefetch', sys.argv[4], 'samp', sys.argv[5], d['value'], d['ms_per_step'])" $1 $2 $3 $4 $5; }
+t 24 16 4 4 6; t 24 18 4 4 4; t 24 19 4 4 4; t 24 20 4 4 3; t 24 16 4 4 3; t 24 20 4 5 3
