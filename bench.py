@@ -288,6 +288,24 @@ def linear_roofline(model, points, batch, flops_per_scene):
             "kernel_ms_per_step": round(total_ms, 3)}
 
 
+def dense_rows_rate(args):
+    """The compact row lists make the throughput depend on how full the balls are.  The bound for clouds whose every ball
+    is full is the same pipeline on the reference's dense (centres x nsample) rows: measured in a child process (the switch
+    is read when the package is imported), same workload, fewer steps."""
+    import subprocess
+    env = dict(os.environ, DET6D_DENSE_ROWS='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '96', '--warmup', '32', '--cpu-scenes', '0', '--no-roofline',
+           '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg, '--streams', str(args.streams),
+           '--group', str(args.group), '--prefetch', str(args.prefetch), '--sampler-streams', str(args.sampler_streams)]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        return {"scenes_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                "note": "DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -429,6 +447,8 @@ def main():
             runners = None  # noqa: F841  (frees the 24 captured graphs before the pipeline leg builds its own)
             torch.cuda.empty_cache()
             line["pipeline"] = pipeline_rate(cfg, model, b, n)
+        if world == 1 and not args.no_roofline and os.environ.get('DET6D_DENSE_ROWS') is None:
+            line["dense_rows"] = dense_rows_rate(args)
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)
