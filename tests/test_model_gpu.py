@@ -179,6 +179,45 @@ def test_pass_group_equals_eager(oracle_ops):
                 assert torch.equal(g['pred_labels'], e['pred_labels'])
 
 
+def test_two_stage_launch_with_producer_and_lazy_coords(oracle_ops):
+    """launch_front() / launch_rest() issued separately with an input PRODUCER (a callable that fills pass.points on the
+    sampler stream, as bench.py's raw-frames leg does), several fronts ahead of the rests; and the lazily built
+    point_coords_list of a captured pass equals the eager one"""
+    from de6d_amd.runtime import load_config, build_model, Det6DGroup
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=5, device='cuda')
+    b, n, k = 2, 2048, 2
+    samp = torch.cuda.Stream()
+    mains = [torch.cuda.Stream() for _ in range(2)]
+    groups = [Det6DGroup(model, b, n, k, samp, main_streams=mains) for _ in range(3)]
+    batches = [torch.from_numpy(flat_points(make_batch(500 + j, b, n))).cuda() for j in range(6)]
+    eager, coords = [], []
+    with torch.no_grad():
+        for pts in batches:
+            bd = {'batch_size': b, 'points': pts}
+            eager.append(model(bd)[0])
+            coords.append([c.clone() for c in bd['point_coords_list']])
+    torch.cuda.synchronize()
+    feed = iter(range(6))
+
+    def produce(r):
+        r.points.copy_(batches[next(feed)], non_blocking=True)
+    for g in groups:                      # all three fronts first (prefetch), then the rests
+        g.launch_front(produce)
+    j = 0
+    for g in groups:
+        for r in g.launch_rest():
+            for got, want in zip(r.finalize(), eager[j]):
+                assert torch.equal(got['pred_boxes'], want['pred_boxes']) and torch.equal(got['pred_scores'], want['pred_scores'])
+            lazy = r.batch_dict['point_coords_list']
+            assert len(lazy) == len(coords[j]) and isinstance(lazy, list)
+            for lvl in range(len(lazy)):
+                assert torch.equal(lazy[lvl], coords[j][lvl])
+            assert torch.equal(lazy[-1], coords[j][-1]) and torch.equal(lazy[0:2][1], coords[j][1])
+            j += 1
+    assert j == 6
+
+
 def test_generic_post_processing_route_matches_fused(oracle_ops):
     """class_agnostic_nms + nms_gpu through the op-level API (the route taken for non-fusable configs)
     selects the same boxes as the fused post-processing kernels and the oracle"""
