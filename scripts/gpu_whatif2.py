@@ -34,6 +34,13 @@ if 'nolinear' in mode:      # GEMM family stubbed out (outputs keep whatever the
             return 0
         return _orig(name, *args)
     fused.L.call = call
+if 'halfk' in mode:          # linear launches with half the reduction length: how GEMM-bound is the pipeline?
+    _lin = fused.linear
+    def half_linear(a, w, shift, act, out, k=None, **kw):
+        kk = w.shape[0] if k is None else k
+        return _lin(a, w, shift, act, out, k=max(4, (kk // 2) // 4 * 4), **kw)
+    fused.linear = half_linear
+    import de6d_amd.pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules as _pm
 if 'nocompact' in mode:
     _orig2 = fused.L.call
     def call2(name, *args):
