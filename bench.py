@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 from de6d_amd.runtime import Det6DGroup, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd.ops import fused  # noqa: E402
 
+MAIN_STREAMS = []              # the pipeline's main streams (reused by the later legs: fresh streams would come from further
+SAMPLER_STREAMS = []           # along PyTorch's stream pool and alias on the hardware queues)
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0
 
@@ -143,8 +145,8 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
     # the same two-stage pipeline as the headline run (main()): stage 1 of a group = the input producer + pack + first
     # sampler of its passes on a sampler stream, issued `prefetch` groups ahead; stage 2 = the rest of every pass
     k, n_main, prefetch = 4, 16, 4
-    mains = [torch.cuda.Stream() for _ in range(n_main)]
-    samp = [torch.cuda.Stream() for _ in range(6)]
+    mains = MAIN_STREAMS[:n_main] if len(MAIN_STREAMS) >= n_main else [torch.cuda.Stream() for _ in range(n_main)]
+    samp = SAMPLER_STREAMS[:6] if len(SAMPLER_STREAMS) >= 6 else [torch.cuda.Stream() for _ in range(6)]
     n_groups = n_main // k + prefetch
     groups = [Det6DGroup(model, batch, n, k, samp[g % len(samp)], main_streams=[mains[(g * k + j) % n_main] for j in range(k)])
               for g in range(n_groups)]
@@ -188,13 +190,16 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
             "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
 
 
-def family_saturated(replay, n_streams=16, reps=24):
+def family_saturated(replay, n_streams=16, reps=24, streams=None):
     """wall time of the GEMM-family launches of one pass re-issued concurrently on n_streams streams.  Every stream
     writes its own copies of the outputs (and reads its own copies of the intermediates), like passes in flight do;
     weights, point rows and row lists are shared, as in the pipeline."""
     if not replay:
         return None
-    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    # the pipeline's own (now idle) main streams when given: fresh ones would come from further along PyTorch's stream
+    # pool and alias on the hardware queues (DESIGN.md §6), which serialises the streams that collide
+    streams = list(streams)[:n_streams] if streams else [torch.cuda.Stream() for _ in range(n_streams)]
+    n_streams = len(streams)
     graphs, keep = [], []
     torch.cuda.synchronize()
     for si, st in enumerate(streams):   # every stream starts at another launch of the pass, as passes in flight do
@@ -227,7 +232,7 @@ def family_saturated(replay, n_streams=16, reps=24):
     return {"seconds": time.perf_counter() - t0, "passes": n_streams * reps, "streams": n_streams, "replays": reps}
 
 
-def linear_roofline(model, points, batch, flops_per_scene):
+def linear_roofline(model, points, batch, flops_per_scene, streams=None):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel + the register chain kernels: the
     SA / head MLP GEMMs) measured live with HIP events on the launch stream over one step.
 
@@ -243,7 +248,7 @@ def linear_roofline(model, points, batch, flops_per_scene):
     torch.cuda.synchronize()
     ev, replay = fused.LINEAR_EVENTS, fused.LINEAR_REPLAY
     fused.LINEAR_EVENTS = fused.LINEAR_REPLAY = None
-    saturated = family_saturated(replay)
+    saturated = family_saturated(replay, streams=streams)
     total_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
     issued = useful = 0.0
     fill = []
@@ -372,7 +377,9 @@ def main():
             # segments) on `depth` main streams.  Every pass still processes its own batch of b scenes.
             n_main = depth
             mains = [torch.cuda.Stream() for _ in range(n_main)]
+            MAIN_STREAMS.extend(mains)
             samp = [torch.cuda.Stream(priority=int(os.environ.get('DET6D_GROUP_PRIO', '0'))) for _ in range(args.sampler_streams)]
+            SAMPLER_STREAMS.extend(samp)
             n_groups = max(1, n_main // k) + args.prefetch
             runners = [Det6DGroup(model, b, n, k, samp[g % len(samp)], points=None if args.h2d else points,
                                   main_streams=[mains[(g * k + j) % n_main] for j in range(k)]) for g in range(n_groups)]
@@ -441,7 +448,7 @@ def main():
                        "streams": depth, "sampler_group": max(1, min(args.group, depth)), "hipgraph": not args.no_graph, "input": "pinned host, H2D per step" if args.h2d else "resident in HBM", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
         }
         if world == 1 and not args.no_roofline:
-            line["roofline"] = linear_roofline(model, points, b, flops)
+            line["roofline"] = linear_roofline(model, points, b, flops, streams=MAIN_STREAMS)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
             line["input_producer"] = input_producer_rate(cfg, b)
             runners = None  # noqa: F841  (frees the 24 captured graphs before the pipeline leg builds its own)
