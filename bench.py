@@ -88,9 +88,32 @@ def index_kernel_rates(model, points, batch, n):
     e[2].record(); F.ball_query_pair(xyz, ctr, shells[0], shells[1]); e[3].record()
     torch.cuda.synchronize()
     t_fps, t_bq = e[0].elapsed_time(e[1]) * 1e-3, e[2].elapsed_time(e[3]) * 1e-3
-    return {"fps_sa1_ms": round(t_fps * 1e3, 3), "fps_pair_evals_per_s": round(batch * (m - 1) * n / t_fps, 0),
-            "ball_query_sa1_ms": round(t_bq * 1e3, 3),
-            "bq_pair_evals_per_s_upper_bound_work": round(2.0 * batch * m * n / t_bq, 0)}
+    out = {"fps_sa1_ms": round(t_fps * 1e3, 3), "fps_pair_evals_per_s": round(batch * (m - 1) * n / t_fps, 0),
+           "ball_query_sa1_ms": round(t_bq * 1e3, 3),
+           "bq_pair_evals_per_s_upper_bound_work": round(2.0 * batch * m * n / t_bq, 0)}
+    # SURVEY.md 8a rows a15 / a13, stand-alone (not on Det6D's FSMSG path): three_nn + three_interpolate of (B, 64, m)
+    # features back onto the n input points (HBM-bound: reads xyz / features, writes (B, 64, n)), rotated NMS of 256 boxes
+    from de6d_amd.ops import pointnet2_batch_hip as pn2
+    from tests.util import random_boxes
+    c = 64
+    feats = torch.randn((batch, c, m), device='cuda')
+    d2 = torch.empty((batch, n, 3), device='cuda')
+    i3 = torch.empty((batch, n, 3), dtype=torch.int32, device='cuda')
+    interp = torch.empty((batch, c, n), device='cuda')
+    w3 = torch.full((batch, n, 3), 1.0 / 3.0, device='cuda')
+    boxes = torch.from_numpy(random_boxes(3, 256)).cuda()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    for rep in range(2):   # second pass is the timed one
+        ev[0].record(); pn2.three_nn_wrapper(batch, n, m, xyz, ctr, d2, i3); ev[1].record()
+        ev[2].record(); pn2.three_interpolate_wrapper(batch, c, m, n, feats, i3, w3, interp); ev[3].record()
+        ev[4].record(); F.nms_device(boxes, 0.1); ev[5].record()
+    torch.cuda.synchronize()
+    t_nn, t_ip, t_nms = (ev[0].elapsed_time(ev[1]) * 1e-3, ev[2].elapsed_time(ev[3]) * 1e-3, ev[4].elapsed_time(ev[5]) * 1e-3)
+    ip_bytes = batch * (c * m * 4 + n * 3 * 8 + c * n * 4)
+    out.update({"three_nn_ms": round(t_nn * 1e3, 3), "three_nn_pair_evals_per_s": round(batch * n * m / t_nn, 0),
+                "three_interpolate_ms": round(t_ip * 1e3, 3), "three_interpolate_GBps": round(ip_bytes / t_ip / 1e9, 1),
+                "nms_256_boxes_us": round(t_nms * 1e6, 1)})
+    return out
 
 
 def input_producer_rate(cfg, batch, n_raw=120000):

@@ -137,9 +137,11 @@ int det6d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float 
 int64_t det6d_nms_mask_words(int boxes_num);
 
 /* Rotated-BEV NMS, fully on device. Replaces nms_gpu (iou3d_nms.cpp:90-136 +
- * iou3d_nms_kernel.cu:267-311): suppression bit-matrix by one wave64 ballot per 64x64 tile,
- * then the greedy scan by a single wave, no host round trip.
- *   boxes (K,7) sorted by descending score; mask (det6d_nms_mask_words(K)) u64 scratch;
+ * iou3d_nms_kernel.cu:267-311): suppression bit-matrix with one wave64 ballot per (box, 64-column block)
+ * = one mask word (K x ceil(K/64) waves over the chip), then the greedy scan by a single wave over rows staged in
+ * LDS, no host round trip.
+ *   boxes (K,7) sorted by descending score; mask (det6d_nms_mask_words(K)) u64 scratch (words of the column blocks
+ *   below a row's own block are never read by the scan and are left unwritten);
  *   keep (K) i64 DEVICE, first *num_keep entries valid; num_keep (1) i32 DEVICE. */
 int det6d_nms(int boxes_num, const float *boxes, float thresh, uint64_t *mask, int64_t *keep,
               int *num_keep, det6d_stream_t stream);
