@@ -30,8 +30,8 @@ def pack_points(points, ld):
     return rows, xyz
 
 
-#: capture controller of runtime.GraphedDet6D: while it is recording, sampler calls are not launched but handed
-#: to it (they replay as eager launches on a high-priority stream between the captured graph segments)
+#: capture controller of runtime.GraphedDet6D (a pass of a Det6DGroup): while it is recording, sampler calls are not
+#: launched but handed to it (the group launches the first sampler of all its passes between their graph segments)
 SAMPLER_SEGMENTS = None
 
 

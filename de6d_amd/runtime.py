@@ -86,27 +86,27 @@ def mlp_flops_per_scene(model, n_points):
 #: Farthest point sampling is ONE 1024-thread workgroup per scene running a 4095-round latency chain.  Inside a
 #: stream of GEMM workgroups at equal queue priority such a workgroup waits 10-20 ms for a CU with enough free
 #: registers / wave slots (scripts/gpu_cumask.py: 3.6 ms alone, 19 ms beside four GEMM streams, 5.5 ms from a
-#: high-priority queue), which kept 22 passes in flight and half the chip's CUs hosting samplers.  HIP gives
-#: high-priority streams only FOUR hardware queues (scripts/gpu_prio_queues.py), so the first sampler — the one
-#: that depends on nothing but the input cloud — is cut out of the captured passes and launched ONCE for a group
-#: of passes on a high-priority stream (Det6DGroup); everything else replays as graph segments at normal priority.
+#: high-priority queue), which kept 22 passes in flight, most of them waiting for a sampler.  HIP gives
+#: high-priority streams only FOUR hardware queues (scripts/gpu_prio_queues.py), so instead the first sampler — the
+#: one that depends on nothing but the input cloud — is cut out of the captured passes and launched ONCE for a group
+#: of passes on a sampler stream, AHEAD of the passes' GEMM stage (Det6DGroup); everything else replays as graph
+#: segments on the main streams.
 SAMPLER_GROUP = 4   # passes per group in bench.py (--group)
 
 
 class _SegmentCapture(object):
-    """capture controller: graph segments on `main`; the first sampler is left to the group (front buffers given),
-    later samplers stay inline unless `eager_rest` (then they replay as eager launches between segments)"""
+    """capture controller: graph segments on `main`; the first sampler is left to the group (whose `front` buffers the
+    pass packs its input into and reads the sampled indices from), later samplers stay inside the graph"""
 
-    def __init__(self, main, pool, front=None, eager_rest=False):
+    def __init__(self, main, pool, front):
         self.main, self.pool = main, pool
-        self.front, self.eager_rest = front, eager_rest
-        self.segments = []          # [(graph, [sampler call, ...])]
+        self.front = front
+        self.segments = []          # [graph, ...]
         self.recording = False
-        self.pack_out = None if front is None else (front[0], front[1])
+        self.pack_out = (front[0], front[1])
         self._graph = self._ctx = None
-        self._calls = None
         self._n_sample = 0
-        self._mode = None
+        self._cut = False
 
     def begin(self):
         self._graph = torch.cuda.CUDAGraph()
@@ -117,45 +117,37 @@ class _SegmentCapture(object):
     def end(self):
         self._graph.capture_end()
         self._ctx.__exit__(None, None, None)
-        self.segments.append((self._graph, []))
+        self.segments.append(self._graph)
         self._graph = self._ctx = None
 
     def sample_index_buffer(self, b, m):
         """index buffer of the next _sample call: the group's for the first sampler, None = allocate as usual"""
-        if self.front is not None and self._n_sample == 0:
+        if self._n_sample == 0:
             assert tuple(self.front[2].shape) == (b, m)
             return self.front[2]
         return None
 
     def enter_samplers(self):
         self._n_sample += 1
-        if self.front is not None and self._n_sample == 1:
-            self._mode = 'front'
-        elif self.eager_rest:
-            self._mode = 'eager'
-        else:
-            self._mode = None
+        self._cut = self._n_sample == 1
+        if not self._cut:
             return
-        self._graph.capture_end()
+        self._graph.capture_end()          # segment 0 ends here; the group launches the sampler between the segments
         self._ctx.__exit__(None, None, None)
-        self._calls = []
         self.recording = True
 
     def add_sampler(self, xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
-        if self._mode == 'front':   # launched by the group for all its passes at once: must be the plain input-only D-FPS
-            if not (scores is None and lo == 0 and hi == xyz.shape[1] and idx_offset == 0 and m == idx_out.shape[1]
-                    and xyz.data_ptr() == self.front[1].data_ptr() and idx_out.data_ptr() == self.front[2].data_ptr()):
-                raise NotImplementedError("grouped first sampler: expected one d-fps over the whole input cloud")
-            return
-        temp = torch.empty((xyz.shape[0], hi - lo), dtype=torch.float32, device=xyz.device)   # owned by the call
-        self._calls.append((xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp))
+        # launched by the group for all its passes at once: must be the plain input-only D-FPS
+        if not (scores is None and lo == 0 and hi == xyz.shape[1] and idx_offset == 0 and m == idx_out.shape[1]
+                and xyz.data_ptr() == self.front[1].data_ptr() and idx_out.data_ptr() == self.front[2].data_ptr()):
+            raise NotImplementedError("grouped first sampler: expected one d-fps over the whole input cloud")
 
     def exit_samplers(self):
-        if self._mode is None:
+        if not self._cut:
             return
+        self._cut = False
         self.recording = False
-        self.segments.append((self._graph, self._calls))
-        self._calls = None
+        self.segments.append(self._graph)
         self.begin()
 
 
@@ -167,15 +159,13 @@ class GraphedDet6D(object):
     The captured graph reads `self.points` (static input, (B*N, 1+3+C)); pass a tensor to launch()
     to have it copied in first, or write into `self.points` yourself."""
 
-    def __init__(self, model, batch_size, n_points, point_width=5, points=None, warmup=2, front=None, hi_stream=None,
-                 stream=None):
+    def __init__(self, model, batch_size, n_points, point_width=5, points=None, warmup=2, front=None, stream=None):
         """front = (rows, xyz, idx) slices of a Det6DGroup: the pass packs its points into them and takes the first
         sampler's indices from idx (the group launches that sampler for all its passes)"""
         from .ops import fused
         self.model = model
         self.batch_size = batch_size
         self.stream = stream if stream is not None else torch.cuda.Stream()
-        self.hi_stream = hi_stream
         self.points = points if points is not None else torch.zeros(
             (batch_size * n_points, point_width), dtype=torch.float32, device='cuda')
         pp = model.model_cfg.POST_PROCESSING
@@ -211,8 +201,6 @@ class GraphedDet6D(object):
             finally:
                 fused.SAMPLER_SEGMENTS = None
             self.segments = ctl.segments
-            self._ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self.segments]
-            self._fps = fused.fps_fused
         else:
             self.graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
@@ -228,30 +216,17 @@ class GraphedDet6D(object):
             points(self)
         elif points is not None and points.data_ptr() != self.points.data_ptr():
             self.points.copy_(points, non_blocking=True)
-        self.segments[0][0].replay()
+        self.segments[0].replay()
 
     def launch_rest(self, sampled):
         """the remaining segments once the group's sampler (event `sampled`) has run"""
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(sampled)
-            self._replay(first=1)
+            for graph in self.segments[1:]:
+                graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
             self.done.record()
         return self
-
-    def _replay(self, first=0):
-        """graph segments on the pass's stream, eager samplers between them on the high-priority stream"""
-        main, hi = self.stream, self.hi_stream
-        for (graph, calls), (e_main, e_hi) in list(zip(self.segments, self._ev))[first:]:
-            graph.replay()
-            if calls:
-                e_main.record(main)
-                hi.wait_event(e_main)
-                with torch.cuda.stream(hi):
-                    for xyz, lo, hi_, m, scores, gamma, idx_out, idx_offset, temp in calls:
-                        self._fps(xyz, lo, hi_, m, scores, gamma, idx_out, idx_offset, temp=temp)
-                e_hi.record(hi)
-                main.wait_event(e_hi)
 
     def launch(self, points=None):
         with torch.cuda.stream(self.stream):
