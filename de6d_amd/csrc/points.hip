@@ -80,7 +80,11 @@ __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
     ux = u[0]; uy = u[1]; uz = u[2];
   }
   const float *kn = known + (size_t)bs * m * 3;
-  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+  // The reference keeps the running bests as double 1e40 and compares float candidates against them; a float candidate
+  // converts to double exactly, so float bests initialised to +inf select the same points (d < 1e40 <=> d < inf for every
+  // float d; an untouched best prints as (float)1e40 = inf either way).  b1 <= b2 <= b3 always holds, which turns the
+  // reference's if / else-if cascade into three independent compares + selects (no divergence, no f64 ops).
+  float best1 = __builtin_inff(), best2 = __builtin_inff(), best3 = __builtin_inff();
   int besti1 = 0, besti2 = 0, besti3 = 0;
   for (int k0 = 0; k0 < m; k0 += 512) {
     const int cnt = min(512, m - k0);
@@ -88,26 +92,21 @@ __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
     for (int t = threadIdx.x; t < cnt * 3; t += blockDim.x) tile[t] = kn[(size_t)k0 * 3 + t];
     __syncthreads();
     if (live) {
+#pragma unroll 4
       for (int kk = 0; kk < cnt; ++kk) {
         const float d = d6_sqdist(ux - tile[kk * 3 + 0], uy - tile[kk * 3 + 1], uz - tile[kk * 3 + 2]);
         const int k = k0 + kk;
-        if (d < best1) {
-          best3 = best2; besti3 = besti2;
-          best2 = best1; besti2 = besti1;
-          best1 = d; besti1 = k;
-        } else if (d < best2) {
-          best3 = best2; besti3 = besti2;
-          best2 = d; besti2 = k;
-        } else if (d < best3) {
-          best3 = d; besti3 = k;
-        }
+        const bool c1 = d < best1, c2 = d < best2, c3 = d < best3;
+        best3 = c2 ? best2 : (c3 ? d : best3);  besti3 = c2 ? besti2 : (c3 ? k : besti3);
+        best2 = c1 ? best1 : (c2 ? d : best2);  besti2 = c1 ? besti1 : (c2 ? k : besti2);
+        best1 = c1 ? d : best1;                 besti1 = c1 ? k : besti1;
       }
     }
   }
   if (live) {
     float *od = dist2 + ((size_t)bs * n + pt) * 3;
     int *oi = idx + ((size_t)bs * n + pt) * 3;
-    od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+    od[0] = best1; od[1] = best2; od[2] = best3;
     oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
   }
 }
