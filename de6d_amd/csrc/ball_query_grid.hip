@@ -59,14 +59,14 @@ __device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell,
 __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, float cell, const float *__restrict__ xyz,
                                                                       GridHeader *__restrict__ hdr,
                                                                       int *__restrict__ cell_start,
-                                                                      int *__restrict__ sorted_idx) {
+                                                                      float4 *__restrict__ sorted_pts) {
   __shared__ int counts[kGridCells];
   __shared__ float red[kBuildThreads / 64];
   __shared__ int wave_tot[kBuildThreads / 64];
   const int tid = threadIdx.x;
   xyz += (size_t)blockIdx.x * n * 3;
   cell_start += (size_t)blockIdx.x * (kGridCells + 1);
-  sorted_idx += (size_t)blockIdx.x * n;
+  sorted_pts += (size_t)blockIdx.x * n;   // (x, y, z, index bits) per sorted position: one 16-byte read per candidate
 
   float xmin = 3e38f, xmax = -3e38f, ymin = 3e38f, ymax = -3e38f;
   for (int k = tid; k < n; k += kBuildThreads) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
     const int cx = cell_coord(xyz[(size_t)k * 3 + 0], xmin, inv, nx);
     const int cy = cell_coord(xyz[(size_t)k * 3 + 1], ymin, inv, ny);
     const int pos = atomicAdd(&counts[cy * nx + cx], 1);
-    sorted_idx[pos] = k;
+    sorted_pts[pos] = make_float4(xyz[(size_t)k * 3 + 0], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2], __int_as_float(k));
   }
 }
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
 __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
     int n, int m, int words, float rin2_a, float rout2_a, int ns_a, float rin2_b, float rout2_b, int ns_b,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, const GridHeader *__restrict__ hdr,
-    const int *__restrict__ cell_start, const int *__restrict__ sorted_idx, int *__restrict__ cnt_a,
+    const int *__restrict__ cell_start, const float4 *__restrict__ sorted_pts, int *__restrict__ cnt_a,
     int *__restrict__ idx_a, int *__restrict__ cnt_b, int *__restrict__ idx_b) {
   extern __shared__ unsigned bitmaps[];            // [kQueryWaves][2][words]
   __shared__ int hits[kQueryWaves][2][kMaxNs];
@@ -150,9 +150,8 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
   unsigned *bm_b = bitmaps + (size_t)(wave * 2 + 1) * words;
   for (int w = lane; w < words; w += 64) { bm_a[w] = 0u; bm_b[w] = 0u; }
   const GridHeader h = hdr[bs];
-  const float *p = xyz + (size_t)bs * n * 3;
   const int *cs = cell_start + (size_t)bs * (kGridCells + 1);
-  const int *si = sorted_idx + (size_t)bs * n;
+  const float4 *si = sorted_pts + (size_t)bs * n;
   const int wpl = (words + 63) / 64;               // bitmap words per lane (contiguous block per lane)
 
   for (int ci = blockIdx.x * kQueryWaves + wave; ci < m; ci += gridDim.x * kQueryWaves) {
@@ -176,9 +175,9 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
         bool ha = false, hb = false;
         int k = 0;
         if (t < end) {
-          k = si[t];
-          const float x = p[(size_t)k * 3 + 0], yy = p[(size_t)k * 3 + 1], z = p[(size_t)k * 3 + 2];
-          const float d2 = d6_sqdist(qx - x, qy - yy, qz - z);
+          const float4 c = si[t];
+          k = __float_as_int(c.w);
+          const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
           ha = d2 >= rin2_a && d2 < rout2_a;
           hb = d2 >= rin2_b && d2 < rout2_b;
         }
@@ -216,9 +215,9 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
     for (int y = y0; y <= y1; ++y) {
       const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];
       for (int t = beg + lane; t < end; t += 64) {
-        const int k = si[t];
-        const float x = p[(size_t)k * 3 + 0], yy = p[(size_t)k * 3 + 1], z = p[(size_t)k * 3 + 2];
-        const float d2 = d6_sqdist(qx - x, qy - yy, qz - z);
+        const float4 c = si[t];
+        const int k = __float_as_int(c.w);
+        const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
         if (d2 >= rin2_a && d2 < rout2_a) atomicOr(&bm_a[k >> 5], 1u << (k & 31));
         if (d2 >= rin2_b && d2 < rout2_b) atomicOr(&bm_b[k >> 5], 1u << (k & 31));
       }
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
 
 DET6D_API int64_t det6d_ball_query_grid_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
-  const int64_t per = 32 + (int64_t)(kGridCells + 1) * 4 + (int64_t)n * 4;
+  const int64_t per = 32 + (int64_t)(kGridCells + 1) * 4 + (int64_t)n * 16;
   return (int64_t)b * ((per + 63) / 64 * 64) + 256;
 }
 
@@ -281,13 +280,13 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
   if (lds > 96 * 1024) return DET6D_EINVAL;        // N <= 98304; use det6d_ball_query_pair beyond
   if (b == 0 || m == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
-  // workspace layout: headers | cell_start | sorted_idx
+  // workspace layout: headers | cell_start | sorted (x, y, z, index) records
   char *ws = (char *)workspace;
   GridHeader *hdr = (GridHeader *)ws;
   size_t off = ((size_t)b * sizeof(GridHeader) + 63) / 64 * 64;
   int *cell_start = (int *)(ws + off);
   off += ((size_t)b * (kGridCells + 1) * 4 + 63) / 64 * 64;
-  int *sorted_idx = (int *)(ws + off);
+  float4 *sorted_pts = (float4 *)(ws + off);
   const float rmax = rout_a > rout_b ? rout_a : rout_b;
   static bool big_lds = false;
   if (lds > 32 * 1024 && !big_lds) {
@@ -297,10 +296,10 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
     big_lds = true;
   }
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start,
-                     sorted_idx);
+                     sorted_pts);
   const int blocks_x = min(det6d_divup(m, kQueryWaves), 1024);
   hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks_x, b), dim3(64 * kQueryWaves), lds, s, n, m, words,
                      rin_a * rin_a, rout_a * rout_a, ns_a, rin_b * rin_b, rout_b * rout_b, ns_b, new_xyz, xyz, hdr,
-                     cell_start, sorted_idx, cnt_a, idx_a, cnt_b, idx_b);
+                     cell_start, sorted_pts, cnt_a, idx_a, cnt_b, idx_b);
   return det6d_check_launch("det6d_ball_query_pair_grid");
 }

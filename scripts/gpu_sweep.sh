@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-t() { GPU_MAX_HW_QUEUES=$1 python bench.py --cpu-scenes 0 --no-roofline --streams $2 --group $3 --prefetch $4 --sampler-streams $5 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('queues', sys.argv[1], 'main', sys.argv[2], 'group', sys.argv[3], 'prefetch', sys.argv[4], 'samp', sys.argv[5], d['value'], d['ms_per_step'])" $1 $2 $3 $4 $5; }
-t 24 16 4 4 3; t 24 18 4 4 3; t 24 18 4 4 2; t 24 17 4 4 3; t 24 16 4 4 2; t 24 19 4 4 2
+timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "ball or grid or model or tiny or waymo or class or sloped or fused" 2>&1 | tail -2
+t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print(sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
+t; t
+bash scripts/gpu_launch_list.sh > /dev/null 2>&1; grep -n "bq_grid" gpurun_out/launch_list/one_pass.txt | cut -c1-100
