@@ -134,6 +134,45 @@ def test_compact_groups_equals_c_oracle(oracle_ops, smin, split):
     np.testing.assert_array_equal(cr.crow_c.cpu().numpy()[:live], oc[:live])
 
 
+@pytest.mark.parametrize("kind", ["all_empty", "all_full", "all_single", "mixed_heavy_tail", "one_centre", "ragged_total"])
+def test_compact_groups_extreme_distributions(oracle_ops, kind):
+    """row lists on degenerate hit-count distributions == the C oracle's, and the MLP over them == the dense oracle"""
+    from de6d_amd.ops import fused
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    b, n, ns = 2, 400, 32
+    m = {"one_centre": 1, "ragged_total": 257}.get(kind, 300)
+    cnt = {"all_empty": np.zeros((b, m)), "all_full": np.full((b, m), ns), "all_single": np.ones((b, m)),
+           "mixed_heavy_tail": np.minimum(rng.zipf(1.5, (b, m)), ns), "one_centre": np.array([[5], [0]]),
+           "ragged_total": rng.integers(0, ns + 1, (b, m))}[kind].astype(np.int32)
+    idx = np.zeros((b, m, ns), np.int32)
+    for bi in range(b):
+        for j in range(m):
+            c = cnt[bi, j]
+            if c:
+                idx[bi, j] = np.sort(rng.choice(n, c, replace=False))[np.arange(ns) % c]
+    for smin, split in ((1, 1), (4, 4)):
+        cr = build_list(fused, cnt, idx, n, smin, split)
+        ohdr, op, oc = oracle_ops.compact_groups(cnt, idx, n, smin=smin, split=split)
+        hdr = cr.hdr.cpu().numpy()
+        np.testing.assert_array_equal(hdr[:10], ohdr[:10])
+        live = int(hdr[0])
+        np.testing.assert_array_equal(cr.crow_p.cpu().numpy()[:live], op[:live])
+        np.testing.assert_array_equal(cr.crow_c.cpu().numpy()[:live], oc[:live])
+    c_in, widths = 1, (32, 32, 64)
+    ld = 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[...] = rng.normal(size=(b, n, ld))
+    ctr = rng.normal(size=(b, m, 3)).astype(np.float32)
+    layers_np, layers_dev = make_layers(rng, ld, c_in, widths)
+    out = torch.zeros((b * m, widths[2]), device="cuda")
+    cr = build_list(fused, cnt, idx, n, 1, 1)
+    fused.mlp_chain3_compact(dev(rows), cr, dev(ctr), layers_dev, out, 0)
+    h = oracle_ops.linear(rows, layers_np[0][0], layers_np[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(h, layers_np[1][0], layers_np[1][1], 1)
+    ref = oracle_ops.linear(h, layers_np[2][0], layers_np[2][1], 1, cnt=cnt, pool=ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
 def make_layers(rng, ld, c_in, widths):
     dims = [ld] + list(widths)
     layers_np, layers_dev = [], []
