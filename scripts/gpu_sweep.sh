@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-DET6D_FPS_DBG=10 timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "fps or skip or sampler" 2>&1 | tail -2
-t() { python bench.py --cpu-scenes 0 $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print('dbg', os.environ.get('DET6D_FPS_DBG'), d['value'], d['ms_per_step'], 'fps alone ms', d['index_kernels']['fps_sa1_ms'])" $*; }
-t; DET6D_FPS_DBG=10 t; t; DET6D_FPS_DBG=10 t
+timeout 1200 python -m pytest tests/test_compact_gpu.py tests/test_model_gpu.py -x -q -m gpu 2>&1 | tail -2
+t() { python bench.py --cpu-scenes 0 --no-roofline $* 2>/dev/null | tail -1 > /tmp/o.json; python -c "import json,sys,os; d=json.load(open('/tmp/o.json')); print(sys.argv[1:], d['value'], d['ms_per_step'])" $*; }
+t; t
+bash scripts/gpu_launch_list.sh > /dev/null 2>&1; grep -n "compact_place" gpurun_out/launch_list/one_pass.txt | cut -c1-100
