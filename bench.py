@@ -14,9 +14,20 @@ per-scene detections materialised on the host side) inside the timed region.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, scenes sharded (weak scaling, 8 scenes per GPU per step), no
-collective on the data path; RCCL is used only for the barrier and the max-over-ranks of the
-elapsed time.  Rank 0 prints ONE JSON line.
+Timing: the pipeline holds up to 32 passes (16 in their GEMM stage + 4 prefetched sampler groups of 4), so a
+sync-bracketed run of K steps is mostly pipeline fill + drain when K is small.  `value` is therefore measured
+over a STEADY-STATE WINDOW: one continuous stream of P + W + K + T steps is issued (P = pre-roll that fills the
+pipeline, W = --warmup, T = tail that keeps it full), with barrier + synchronize before and after the stream,
+and the clock runs from the finalisation of step P+W-1 to the finalisation of step P+W+K-1: exactly K steps are
+finalised (detections of every scene materialised) inside the window.  The sync-bracketed time of K steps on an
+empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the timed region
+every pass's last result is compared with an eager pass over the same batch (`selfcheck`); a mismatch exits
+non-zero.
+
+N > 1: one process per GPU, scenes sharded (weak scaling, 8 scenes per GPU per step), no collective on the data
+path; RCCL is used only for the barrier and the max-over-ranks of the window time.  Without torchrun
+(`WORLD_SIZE` unset) `--gpus N` starts the N rank processes itself, before anything touches the GPU.  Rank 0
+prints ONE JSON line.
 """
 import argparse
 import json
@@ -37,8 +48,9 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from de6d_amd.runtime import Det6DGroup, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
+from de6d_amd.runtime import ScenePipeline, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd.ops import fused  # noqa: E402
+from de6d_amd import synthetic  # noqa: E402
 
 MAIN_STREAMS = []              # the pipeline's main streams (reused by the later legs: fresh streams would come from further
 SAMPLER_STREAMS = []           # along PyTorch's stream pool and alias on the hardware queues)
@@ -46,11 +58,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 HBM_PEAK_GBS = 8000.0
 
 
-def synth_points(seed0, b, n, tilt=False):
-    from tests.util import make_batch
-    batch = make_batch(seed0, b, n, tilt=tilt)
-    bidx = np.repeat(np.arange(b, dtype=np.float32), n)[:, None]
-    return np.concatenate([bidx, batch.reshape(b * n, 4)], 1).astype(np.float32)
+def synth_points(seed0, b, n, tilt=False, scene='uniform'):
+    make = synthetic.beam_batch if scene == 'beam' else synthetic.make_batch
+    return synthetic.points_tensor(make(seed0, b, n, tilt=tilt))
 
 
 def cpu_baseline(cfg, model, pts_np, scenes):
@@ -148,9 +158,9 @@ def input_producer_rate(cfg, batch, n_raw=120000):
             "frac": round(alg / sec / 8e12, 4)}
 
 
-def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
-    """raw frames -> annotations: det6d_prepare_points (f1) -> captured Det6D graph -> det6d_kitti_annos + one
-    D2H + host dictionaries (f2), `depth` batches in flight; raw frames resident in HBM like the headline run"""
+def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000):
+    """raw frames -> annotations: det6d_prepare_points (f1) -> captured Det6D passes -> det6d_kitti_annos + one
+    D2H + host dictionaries (f2) through the same two-stage pipeline as the headline run; raw frames resident in HBM"""
     from de6d_amd.ops import fused as F
     from de6d_amd.pcdet.datasets import KittiDataset
     from de6d_amd.pcdet.utils.calibration_kitti import Calibration
@@ -165,52 +175,33 @@ def pipeline_rate(cfg, model, batch, n, depth=24, steps=144, n_raw=120000):
                          'Tr_velo2cam': np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)})
     meta = {'calib': [calib] * batch, 'image_shape': np.tile(np.array([[375, 1242]], np.int32), (batch, 1)),
             'frame_id': ['%06d' % i for i in range(batch)]}
-    # the same two-stage pipeline as the headline run (main()): stage 1 of a group = the input producer + pack + first
-    # sampler of its passes on a sampler stream, issued `prefetch` groups ahead; stage 2 = the rest of every pass
-    k, n_main, prefetch = 4, 16, 4
-    mains = MAIN_STREAMS[:n_main] if len(MAIN_STREAMS) >= n_main else [torch.cuda.Stream() for _ in range(n_main)]
-    samp = SAMPLER_STREAMS[:6] if len(SAMPLER_STREAMS) >= 6 else [torch.cuda.Stream() for _ in range(6)]
-    n_groups = n_main // k + prefetch
-    groups = [Det6DGroup(model, batch, n, k, samp[g % len(samp)], main_streams=[mains[(g * k + j) % n_main] for j in range(k)])
-              for g in range(n_groups)]
+    pipe = ScenePipeline(model, batch, n, n_main=16, group=4, prefetch=4, sampler_streams=6,
+                         main_streams=MAIN_STREAMS[:16] or None, samplers=SAMPLER_STREAMS[:6] or None)
     scratch = {}
-    for grp in groups:
-        for r in grp.runners:
-            scratch[id(r)] = (torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
-                              torch.empty((batch,), dtype=torch.int32, device='cuda'))
+    for r in pipe.passes:
+        scratch[id(r)] = (torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
+                          torch.empty((batch,), dtype=torch.int32, device='cuda'))
     seed = [0]
+    annos = [0]
 
     def produce(r):
         ws, cnt = scratch[id(r)]
         seed[0] += 1
         F.prepare_points(raw, offsets, dc.POINT_CLOUD_RANGE, n, seed=seed[0], out=r.points, workspace=ws, n_in=cnt)
 
-    def run(steps_):
-        ngl = (steps_ + k - 1) // k
-        inflight, n_annos = [], 0
-        for g in range(min(prefetch, ngl)):
-            groups[g % n_groups].launch_front(produce)
-        for g in range(ngl):
-            if len(inflight) >= n_groups - prefetch:
-                for r in inflight.pop(0):
-                    n_annos += len(KittiDataset.generate_prediction_dicts(meta, r.finalize(), cfg.CLASS_NAMES))
-            if g + prefetch < ngl:
-                groups[(g + prefetch) % n_groups].launch_front(produce)
-            inflight.append(groups[g % n_groups].launch_rest())
-        for grp in inflight:
-            for r in grp:
-                n_annos += len(KittiDataset.generate_prediction_dicts(meta, r.finalize(), cfg.CLASS_NAMES))
-        return n_annos
+    def consume(step, r, preds):
+        annos[0] += len(KittiDataset.generate_prediction_dicts(meta, preds, cfg.CLASS_NAMES))
 
-    depth = n_main
-    run(depth * 2)
+    pipe.run(32, feed=produce, on_done=consume)
     torch.cuda.synchronize()
+    annos[0] = 0
     t0 = time.perf_counter()
-    frames = run(steps)
+    pipe.run(steps, feed=produce, on_done=consume)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"scenes_per_s": round(frames / dt, 1), "ms_per_batch": round(dt / ((steps + k - 1) // k * k) * 1e3, 3), "batches_in_flight": depth,
-            "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D graph -> kitti_annos -> annotation dicts (host)" % n_raw}
+    return {"scenes_per_s": round(annos[0] / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3), "steps": steps,
+            "timing": "sync-bracketed (fill + drain included)",
+            "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D passes -> kitti_annos -> annotation dicts (host)" % n_raw}
 
 
 def family_saturated(replay, n_streams=16, reps=24, streams=None):
@@ -316,22 +307,101 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
             "kernel_ms_per_step": round(total_ms, 3)}
 
 
-def dense_rows_rate(args):
-    """The compact row lists make the throughput depend on how full the balls are.  The bound for clouds whose every ball
-    is full is the same pipeline on the reference's dense (centres x nsample) rows: measured in a child process (the switch
-    is read when the package is imported), same workload, fewer steps."""
+def child_rate(args, env_extra, extra_args=(), note=""):
+    """the same bench (same steps / warmup / pipeline shape) in a child process with another switch or workload; the
+    parent's GPU state is untouched (the child is a fresh process, nothing is exec'd from this one)"""
     import subprocess
-    env = dict(os.environ, DET6D_DENSE_ROWS='1')
-    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '96', '--warmup', '32', '--cpu-scenes', '0', '--no-roofline',
-           '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg, '--streams', str(args.streams),
-           '--group', str(args.group), '--prefetch', str(args.prefetch), '--sampler-streams', str(args.sampler_streams)]
+    env = dict(os.environ, **env_extra)
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
+           '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch),
+           '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + list(extra_args)
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"scenes_per_s": d["value"], "ms_per_step": d["ms_per_step"],
-                "note": "DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does"}
+        res = {"scenes_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+               "selfcheck": d.get("selfcheck"), "cold_scenes_per_s": d.get("cold", {}).get("scenes_per_s")}
+        if "compact_fill" in d:
+            res["compact_fill"] = d["compact_fill"]
+        if note:
+            res["note"] = note
+        return res
     except Exception as e:  # noqa: BLE001
-        return {"error": repr(e)[:200]}
+        return {"error": repr(e)[:300]}
+
+
+def compact_fill(model, points, batch):
+    """information rows / dense rows of every radius group of one eager pass (how full the balls are: the compact row
+    lists evaluate only the information rows, so throughput depends on it)"""
+    fused.LINEAR_EVENTS, fused.LINEAR_REPLAY = [], None
+    with torch.no_grad():
+        model({'batch_size': batch, 'points': points})
+    torch.cuda.synchronize()
+    ev, fused.LINEAR_EVENTS = fused.LINEAR_EVENTS, None
+    names, nsamples = [], []
+    for li, sa in enumerate(list(model.backbone_3d.SA_modules) + [model.point_head.SA_module]):
+        for gi, ns in enumerate(sa.nsamples):
+            names.append("%s-%s" % ("SA%d" % (li + 1) if li < len(model.backbone_3d.SA_modules) else "head", "AB"[gi] if gi < 2 else gi))
+            nsamples.append(ns)
+    seen, out = set(), []
+    for _, _, r, _, _ in ev:                      # the groups' lists appear in model order
+        if torch.is_tensor(r) and r.data_ptr() not in seen:
+            seen.add(r.data_ptr())
+            h = r.cpu().tolist()
+            gi = len(out)
+            ns = nsamples[gi] if gi < len(nsamples) else None
+            out.append({"group": names[gi] if gi < len(names) else str(gi), "centres": h[7], "nsample": ns, "information_rows": h[8],
+                        "issued_rows": h[0], "fill": round(h[8] / float(h[7] * ns), 4) if ns and h[7] else None})
+    return out
+
+
+def selfcheck(model, pipe, b):
+    """every pass's LAST finalised result against an eager pass over the same batch, bit for bit (the captured segments,
+    the grouped first sampler and the stream choreography must not change a single detection)"""
+    bad, total = [], 0
+    with torch.no_grad():
+        for i, r in enumerate(pipe.passes):
+            got = r.finalize()
+            want, _ = model({'batch_size': b, 'points': r.points})
+            torch.cuda.synchronize()
+            for sc, (g, w) in enumerate(zip(got, want)):
+                total += 1
+                same = (g['pred_boxes'].shape == w['pred_boxes'].shape and torch.equal(g['pred_boxes'], w['pred_boxes'])
+                        and torch.equal(g['pred_scores'], w['pred_scores']) and torch.equal(g['pred_labels'], w['pred_labels']))
+                if not same:
+                    bad.append((i, sc))
+    return bad, total
+
+
+def spawn_ranks(n):
+    """--gpus N without torchrun: start the N rank processes (fresh interpreters, nothing in this one has touched the
+    GPU) and return the worst exit code.  Mirrors what core/tools/test.py:137-143 gets from its launcher."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def device_identity():
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = getattr(pr, 'uuid', None)
+    return "%s|%s" % (torch.cuda.current_device(), ident if ident is not None else getattr(pr, 'pci_bus_id', '?'))
 
 
 def main():
@@ -344,118 +414,167 @@ def main():
     ap.add_argument('--streams', type=int, default=16, help='main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
     ap.add_argument('--prefetch', type=int, default=4, help='groups whose sampler stage is issued ahead of the GEMM stage')
     ap.add_argument('--sampler-streams', type=int, default=6)
-    ap.add_argument('--group', type=int, default=4, help='passes whose first (input-only) sampler runs as one high-priority launch; 1 = every pass is a single captured graph')
+    ap.add_argument('--group', type=int, default=4, help='passes whose first (input-only) sampler runs as one launch; 0 = every pass is a single captured graph')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
+    ap.add_argument('--scene', default='uniform', choices=['uniform', 'beam'], help='synthetic scene generator (de6d_amd/synthetic.py)')
+    ap.add_argument('--tilt', action='store_true', help='sloped scenes (BASELINE configs[2])')
+    ap.add_argument('--distinct-batches', type=int, default=8, help='different resident batches the passes cycle through')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-legs', action='store_true', help='skip the child-process legs (dense rows, other BASELINE configs)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
     ap.add_argument('--h2d', action='store_true', help='PCIe-inclusive variant: every step uploads its batch from pinned host memory (never the headline value)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))       # nothing above has initialised HIP
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
+    ranks_seen = [device_identity()]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('DET6D_BENCH_BACKEND', 'nccl')  # 'nccl' IS RCCL on ROCm; gloo only for dry runs
         dist.init_process_group(backend, rank=rank, world_size=world)
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, device_identity())
 
     cfg = load_config(args.cfg)
     model = build_model(cfg, seed=1234, device='cuda')
     b, n = args.batch, args.points
-    pts_np = synth_points(1000 + rank * b, b, n)
-    points = torch.from_numpy(pts_np).cuda()
+    # every rank its own scenes; the passes in flight cycle through `distinct_batches` different resident batches
+    n_distinct = max(1, args.distinct_batches)
+    batches_np = [synth_points(1000 + (rank * n_distinct + i) * b, b, n, tilt=args.tilt, scene=args.scene) for i in range(n_distinct)]
+    batches = [torch.from_numpy(p).cuda() for p in batches_np]
+    pts_np, points = batches_np[0], batches[0]
     depth = max(1, args.streams)
     with torch.no_grad():
         model({'batch_size': b, 'points': points})  # fold weights, load code objects
     torch.cuda.synchronize()
-    runners = None
+
+    pipe = None
     if args.no_graph:
         streams = [torch.cuda.Stream() for _ in range(depth)]
 
-        def run(steps):
-            inflight, dets = [], 0
+        def run(steps, on_done=None):
+            inflight, done = [], 0
             with torch.no_grad():
                 for i in range(steps):
                     if len(inflight) >= depth:
-                        dets += sum(len(p['pred_scores']) for p in model.finalize(inflight.pop(0)))
+                        preds = model.finalize(inflight.pop(0))
+                        if on_done:
+                            on_done(done, None, preds)
+                        done += 1
                     with torch.cuda.stream(streams[i % depth]):
-                        inflight.append(model.forward_async({'batch_size': b, 'points': points}))
+                        inflight.append(model.forward_async({'batch_size': b, 'points': batches[i % n_distinct]}))
                 for h in inflight:
-                    dets += sum(len(p['pred_scores']) for p in model.finalize(h))
-            return dets
-    else:
-        # one captured hipGraph per stream, all reading the same resident input batch
+                    preds = model.finalize(h)
+                    if on_done:
+                        on_done(done, None, preds)
+                    done += 1
+            return done
+        capacity, k = depth, 1
+    elif args.group > 0:
         host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
-        k = max(1, min(args.group, depth))
-        if k >= 1 and args.group > 0:
-            # two-stage software pipeline: stage 1 = pack + first sampler of a group of k passes, one launch on a
-            # sampler stream, issued `prefetch` groups ahead; stage 2 = the rest of each pass (captured graph
-            # segments) on `depth` main streams.  Every pass still processes its own batch of b scenes.
-            n_main = depth
-            mains = [torch.cuda.Stream() for _ in range(n_main)]
-            MAIN_STREAMS.extend(mains)
-            samp = [torch.cuda.Stream(priority=int(os.environ.get('DET6D_GROUP_PRIO', '0'))) for _ in range(args.sampler_streams)]
-            SAMPLER_STREAMS.extend(samp)
-            n_groups = max(1, n_main // k) + args.prefetch
-            runners = [Det6DGroup(model, b, n, k, samp[g % len(samp)], points=None if args.h2d else points,
-                                  main_streams=[mains[(g * k + j) % n_main] for j in range(k)]) for g in range(n_groups)]
+        pipe = ScenePipeline(model, b, n, n_main=depth, group=args.group, prefetch=args.prefetch,
+                             sampler_streams=args.sampler_streams, points=None if args.h2d else batches)
+        MAIN_STREAMS.extend(pipe.main_streams)
+        SAMPLER_STREAMS.extend(pipe.sampler_streams)
 
-            def run(steps):
-                counts, left = [], steps
-                while left > 0:
-                    counts.append(min(k, left)); left -= counts[-1]
-                dets, inflight = 0, []
-                for g in range(min(args.prefetch, len(counts))):
-                    runners[g % n_groups].launch_front(host_batch, counts[g])
-                for g in range(len(counts)):
-                    if len(inflight) >= n_groups - args.prefetch:
-                        dets += sum(len(p['pred_scores']) for r in inflight.pop(0) for p in r.finalize())
-                    if g + args.prefetch < len(counts):
-                        runners[(g + args.prefetch) % n_groups].launch_front(host_batch, counts[g + args.prefetch])
-                    inflight.append(runners[g % n_groups].launch_rest())
-                for grp in inflight:
-                    dets += sum(len(p['pred_scores']) for r in grp for p in r.finalize())
-                return dets
-        else:
-            runners = [GraphedDet6D(model, b, n, points=None if args.h2d else points) for _ in range(depth)]
+        def run(steps, on_done=None):
+            return pipe.run(steps, feed=host_batch, on_done=on_done)
+        capacity, k = len(pipe.passes), pipe.k
+    else:
+        host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
+        runners = [GraphedDet6D(model, b, n, points=None if args.h2d else batches[i % n_distinct]) for i in range(depth)]
+        for r in runners:
+            r.launch(host_batch)
+        for r in runners:
+            r.finalize()
 
-            def run(steps):
-                inflight, dets = [], 0
-                for i in range(steps):
-                    r = runners[i % depth]
-                    if len(inflight) >= depth:
-                        dets += sum(len(p['pred_scores']) for p in inflight.pop(0).finalize())
-                    inflight.append(r.launch(host_batch))
-                for r in inflight:
-                    dets += sum(len(p['pred_scores']) for p in r.finalize())
-                return dets
+        def run(steps, on_done=None):
+            inflight, done = [], 0
+            for i in range(steps):
+                if len(inflight) >= depth:
+                    r0 = inflight.pop(0)
+                    preds = r0.finalize()
+                    if on_done:
+                        on_done(done, r0, preds)
+                    done += 1
+                inflight.append(runners[i % depth].launch(host_batch))
+            for r0 in inflight:
+                preds = r0.finalize()
+                if on_done:
+                    on_done(done, r0, preds)
+                done += 1
+            return done
+        capacity, k = depth, 1
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    def bracket():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the timed region: a steady-state window of exactly args.steps finalised steps --------------------------------
+    preroll = 2 * capacity
+    preroll += (-(preroll + args.warmup)) % k        # the window starts on a group boundary
+    tail = capacity
+    first, last = preroll + args.warmup - 1, preroll + args.warmup + args.steps - 1
+    stamps, dets = {}, [0]
+
+    def on_done(step, r, preds):
+        if step == first or step == last:
+            stamps[step] = time.perf_counter()
+        if first < step <= last:
+            dets[0] += sum(len(p['pred_scores']) for p in preds)
+
+    bracket()
+    t_stream = time.perf_counter()
+    run(preroll + args.warmup + args.steps + tail, on_done)
+    bracket()
+    t_stream = time.perf_counter() - t_stream
+    elapsed_own = stamps[last] - stamps[first]
+    elapsed = elapsed_own
+
+    # ---- cold: K steps on an EMPTY pipeline, synchronize on both sides (fill + drain inside) ----------------------------
+    bracket()
     t0 = time.perf_counter()
     run(args.steps)
-    torch.cuda.synchronize()
+    bracket()
+    cold = time.perf_counter() - t0
+
+    per_rank = [round(args.steps * b / elapsed_own, 1)]
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([elapsed, cold], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, cold = float(t[0].item()), float(t[1].item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(args.steps * b / elapsed_own, 1))
+
+    # ---- self-check: what was timed is what the eager model computes ------------------------------------------------------
+    check = "skipped"
+    if pipe is not None and not args.h2d:
+        bad, total = selfcheck(model, pipe, b)
+        check = "ok" if not bad else "MISMATCH in (pass, scene) %s" % bad[:8]
+        if rank == 0 or bad:
+            print("selfcheck rank %d: %d scenes of %d passes compared with the eager model: %s" % (rank, total, len(pipe.passes), check),
+                  file=sys.stderr, flush=True)
+        if bad:
+            raise SystemExit(3)
 
     if rank == 0:
         flops = mlp_flops_per_scene(model, n)
+        knobs = {k_: v for k_, v in os.environ.items() if k_.startswith('DET6D_')}
         line = {
             "metric": "scenes/sec (16384-pt KITTI) at 1/2/4/8 MI355X; 3D mAP parity vs ref",
             "value": round(world * args.steps * b / elapsed, 2),
@@ -467,18 +586,45 @@ def main():
             "config": {"workload": "KITTI-like Car-only scenes, batch=%d x %d points per GPU per step, Det6D "
                                    "(3-layer FSMSG SA + 6-DoF vote head + rotated NMS), random-init seeded "
                                    "weights; BASELINE.json configs[1]" % (b, n),
-                       "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n,
-                       "streams": depth, "sampler_group": max(1, min(args.group, depth)), "hipgraph": not args.no_graph, "input": "pinned host, H2D per step" if args.h2d else "resident in HBM", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "scene-sharded x%d, no collective" % world},
+                       "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n, "scene_generator": args.scene,
+                       "tilt": args.tilt, "distinct_resident_batches": n_distinct,
+                       "timing": "steady-state window: one continuous stream of %d pre-roll + %d warmup + %d timed + %d tail steps "
+                                 "between barrier+synchronize; clock from the finalisation of step %d to that of step %d (exactly "
+                                 "%d steps finalised inside)" % (preroll, args.warmup, args.steps, tail, first, last, args.steps),
+                       "preroll_steps": preroll, "tail_steps": tail,
+                       "streams": depth, "sampler_group": k, "hipgraph": not args.no_graph,
+                       "input": "pinned host, H2D per step" if args.h2d else "resident in HBM",
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "env_knobs": knobs,
+                       "parallelism": "scene-sharded x%d, no collective" % world},
+            "selfcheck": check,
+            "ranks_seen": ranks_seen, "per_rank_scenes_per_s": per_rank,
+            "stream_total_s": round(t_stream, 4), "detections_in_window": dets[0],
+            "cold": {"scenes_per_s": round(world * args.steps * b / cold, 2), "ms_per_step": round(cold / args.steps * 1e3, 4),
+                     "note": "the same %d steps on an empty pipeline, barrier+synchronize on both sides: pipeline fill + drain included" % args.steps},
         }
+        if world == 1:
+            lat = GraphedDet6D(model, b, n, points=points)
+            lat.launch(); lat.finalize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                lat.launch(); lat.finalize()
+            line["latency"] = {"ms_per_batch": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                               "note": "one batch of %d scenes, one captured graph on one stream, idle chip" % b}
+            del lat
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, points, b, flops, streams=MAIN_STREAMS)
+            line["compact_fill"] = compact_fill(model, points, b)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
             line["input_producer"] = input_producer_rate(cfg, b)
-            runners = None  # noqa: F841  (frees the 24 captured graphs before the pipeline leg builds its own)
+            pipe = None  # noqa: F841  (frees the captured graphs before the pipeline leg builds its own)
             torch.cuda.empty_cache()
             line["pipeline"] = pipeline_rate(cfg, model, b, n)
-        if world == 1 and not args.no_roofline and os.environ.get('DET6D_DENSE_ROWS') is None:
-            line["dense_rows"] = dense_rows_rate(args)
+        elif world == 1:
+            line["compact_fill"] = compact_fill(model, points, b)
+        if world == 1 and not args.no_legs and os.environ.get('DET6D_DENSE_ROWS') is None:
+            line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
+                                            note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
+                                                 "the bound for clouds whose every ball is full")
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

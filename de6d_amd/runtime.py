@@ -272,7 +272,8 @@ class Det6DGroup(object):
         self.runners = []
         for j in range(k):
             sl = slice(j * batch_size, (j + 1) * batch_size)
-            self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=points,
+            own = points[j % len(points)] if isinstance(points, (list, tuple)) else points   # a static input per pass
+            self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=own,
                                              front=(self.rows_all[sl], self.xyz_all[sl], self.idx_all[sl]),
                                              stream=None if main_streams is None else main_streams[j % len(main_streams)]))
         self._fps = fused.fps_fused
@@ -297,3 +298,85 @@ class Det6DGroup(object):
 
     def launch(self, points=None, count=None):
         return self.launch_front(points, count).launch_rest()
+
+
+def warn_hw_queues(need):
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the
+    runtime initialises: with fewer queues than streams the passes in flight serialise"""
+    have = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    if have < need:
+        import warnings
+        warnings.warn("GPU_MAX_HW_QUEUES=%d but the pipeline uses %d HIP streams: they will alias onto the hardware "
+                      "queues and serialise; export GPU_MAX_HW_QUEUES=24 before the process touches the GPU" % (have, need),
+                      RuntimeWarning, stacklevel=3)
+    return have
+
+
+class ScenePipeline(object):
+    """The throughput runner: batches of scenes stream through `n_main / group + prefetch` Det6DGroups.
+    Stage 1 of a group (pack + first sampler of its `group` passes) is issued `prefetch` groups ahead on one of the
+    sampler streams, stage 2 (the captured rest of every pass) on `n_main` main streams; a pass is finalised (its
+    detections sliced per scene, the only host sync) when the slot it occupies is needed again.
+
+    points: None — every pass owns a static input buffer (`passes[i].points`) the caller fills or copies into;
+            a tensor — every pass reads it; a list of tensors — pass i reads points[i % len(points)]."""
+
+    def __init__(self, model, batch_size, n_points, n_main=16, group=4, prefetch=4, sampler_streams=6, points=None,
+                 point_width=5, main_streams=None, samplers=None):
+        self.k = max(1, min(group, n_main))
+        self.prefetch = prefetch
+        warn_hw_queues(n_main + sampler_streams)
+        self.main_streams = list(main_streams) if main_streams else [torch.cuda.Stream() for _ in range(n_main)]
+        self.sampler_streams = list(samplers) if samplers else [torch.cuda.Stream() for _ in range(sampler_streams)]
+        n_main = len(self.main_streams)
+        self.n_groups = max(1, n_main // self.k) + prefetch
+        self.groups = []
+        for g in range(self.n_groups):
+            own = points
+            if isinstance(points, (list, tuple)):
+                own = [points[(g * self.k + j) % len(points)] for j in range(self.k)]
+            self.groups.append(Det6DGroup(model, batch_size, n_points, self.k, self.sampler_streams[g % len(self.sampler_streams)],
+                                          point_width=point_width, points=own,
+                                          main_streams=[self.main_streams[(g * self.k + j) % n_main] for j in range(self.k)]))
+        self.passes = [r for grp in self.groups for r in grp.runners]
+        self.prime()
+
+    def prime(self):
+        """every group once through both stages (first launch of each captured graph, code objects, workspaces), so that
+        no later run pays for it whatever its length"""
+        for grp in self.groups:
+            grp.launch()
+        for r in self.passes:
+            r.finalize()
+        torch.cuda.synchronize()
+
+    def run(self, steps, feed=None, on_done=None):
+        """`steps` passes through the pipeline; `feed` (host tensor or callable(pass)) supplies the input of a pass whose
+        static buffer is not resident already; on_done(step, pass, pred_dicts) is called in step order as passes are
+        finalised.  Returns the number of passes finalised (== steps)."""
+        k, n_groups, prefetch = self.k, self.n_groups, self.prefetch
+        counts, left = [], steps
+        while left > 0:
+            counts.append(min(k, left))
+            left -= counts[-1]
+        done, inflight = 0, []
+
+        def finish(active):
+            nonlocal done
+            for r in active:
+                preds = r.finalize()
+                if on_done is not None:
+                    on_done(done, r, preds)
+                done += 1
+
+        for g in range(min(prefetch, len(counts))):
+            self.groups[g % n_groups].launch_front(feed, counts[g])
+        for g in range(len(counts)):
+            if len(inflight) >= n_groups - prefetch:
+                finish(inflight.pop(0))
+            if g + prefetch < len(counts):
+                self.groups[(g + prefetch) % n_groups].launch_front(feed, counts[g + prefetch])
+            inflight.append(self.groups[g % n_groups].launch_rest())
+        for active in inflight:
+            finish(active)
+        return done
