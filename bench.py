@@ -419,6 +419,8 @@ def main():
     ap.add_argument('--scene', default='uniform', choices=['uniform', 'beam'], help='synthetic scene generator (de6d_amd/synthetic.py)')
     ap.add_argument('--tilt', action='store_true', help='sloped scenes (BASELINE configs[2])')
     ap.add_argument('--distinct-batches', type=int, default=8, help='different resident batches the passes cycle through')
+    ap.add_argument('--windows', type=int, default=17, help='overlapping K-step windows in the stream; the median one is the timed region')
+    ap.add_argument('--preroll', type=int, default=-1, help='pre-roll length in pipeline capacities (default 8)')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-legs', action='store_true', help='skip the child-process legs (dense rows, other BASELINE configs)')
@@ -524,25 +526,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the timed region: a steady-state window of exactly args.steps finalised steps --------------------------------
-    preroll = 2 * capacity
-    preroll += (-(preroll + args.warmup)) % k        # the window starts on a group boundary
+    # ---- the timed region: steady-state windows of exactly args.steps finalised steps -----------------------------------
+    # Passes complete in bursts (a group of 4 at a time, groups often in pairs), so ONE window of a few groups is +-17 %
+    # noisy (measured).  The stream therefore carries R overlapping windows, each "finalisation of step s to finalisation
+    # of step s + K" with s on consecutive group boundaries, and the MEDIAN window is the timed region.
+    preroll = (args.preroll if args.preroll >= 0 else 8) * capacity   # long enough for clocks / power to settle (~0.2 s)
+    preroll += (-(preroll + args.warmup)) % k        # the windows start on group boundaries
+    n_windows = max(1, args.windows)
     tail = capacity
-    first, last = preroll + args.warmup - 1, preroll + args.warmup + args.steps - 1
+    first = preroll + args.warmup - 1
+    last = first + (n_windows - 1) * k + args.steps
     stamps, dets = {}, [0]
 
     def on_done(step, r, preds):
-        if step == first or step == last:
+        if first <= step <= last:
             stamps[step] = time.perf_counter()
-        if first < step <= last:
+        if first < step <= first + args.steps:
             dets[0] += sum(len(p['pred_scores']) for p in preds)
 
     bracket()
+    GraphedDet6D.host_wait_s = 0.0
     t_stream = time.perf_counter()
-    run(preroll + args.warmup + args.steps + tail, on_done)
+    run(last + 1 + tail, on_done)
     bracket()
     t_stream = time.perf_counter() - t_stream
-    elapsed_own = stamps[last] - stamps[first]
+    host_wait = GraphedDet6D.host_wait_s
+    windows = sorted(stamps[first + j * k + args.steps] - stamps[first + j * k] for j in range(n_windows))
+    elapsed_own = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
     elapsed = elapsed_own
 
     # ---- cold: K steps on an EMPTY pipeline, synchronize on both sides (fill + drain inside) ----------------------------
@@ -588,17 +598,20 @@ def main():
                                    "weights; BASELINE.json configs[1]" % (b, n),
                        "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n, "scene_generator": args.scene,
                        "tilt": args.tilt, "distinct_resident_batches": n_distinct,
-                       "timing": "steady-state window: one continuous stream of %d pre-roll + %d warmup + %d timed + %d tail steps "
-                                 "between barrier+synchronize; clock from the finalisation of step %d to that of step %d (exactly "
-                                 "%d steps finalised inside)" % (preroll, args.warmup, args.steps, tail, first, last, args.steps),
-                       "preroll_steps": preroll, "tail_steps": tail,
+                       "timing": "steady-state: one continuous stream of %d steps (%d pre-roll, %d warmup, then the windows, %d tail) "
+                                 "between barrier+synchronize; a window = finalisation of step s to finalisation of step s+%d "
+                                 "(exactly %d steps finalised inside); value = median of %d windows starting on consecutive "
+                                 "group boundaries" % (last + 1 + tail, preroll, args.warmup, tail, args.steps, args.steps, n_windows),
+                       "preroll_steps": preroll, "tail_steps": tail, "windows": n_windows,
+                       "window_ms_min_median_max": [round(windows[0] * 1e3, 3), round(elapsed_own * 1e3, 3), round(windows[-1] * 1e3, 3)],
                        "streams": depth, "sampler_group": k, "hipgraph": not args.no_graph,
                        "input": "pinned host, H2D per step" if args.h2d else "resident in HBM",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "env_knobs": knobs,
                        "parallelism": "scene-sharded x%d, no collective" % world},
             "selfcheck": check,
             "ranks_seen": ranks_seen, "per_rank_scenes_per_s": per_rank,
-            "stream_total_s": round(t_stream, 4), "detections_in_window": dets[0],
+            "stream_total_s": round(t_stream, 4), "host_blocked_frac": round(host_wait / t_stream, 3),
+            "detections_in_window": dets[0],
             "cold": {"scenes_per_s": round(world * args.steps * b / cold, 2), "ms_per_step": round(cold / args.steps * 1e3, 4),
                      "note": "the same %d steps on an empty pipeline, barrier+synchronize on both sides: pipeline fill + drain included" % args.steps},
         }

@@ -37,16 +37,20 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    objdir = os.path.join(CSRC, "build")
+def build(force=False, verbose=False, experiments=False):
+    """experiments=True: a SEPARATE library (libdet6d_hip_experiments.so) compiled with -DDET6D_EXPERIMENTS, in which the
+    tile-sweep / timing / stand-in environment variables of scripts/experiments are live.  The shipped library ignores them."""
+    objdir = os.path.join(CSRC, "build_experiments" if experiments else "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    flags = FLAGS + (["-DDET6D_EXPERIMENTS"] if experiments else [])
+    lib = LIB.replace(".so", "_experiments.so") if experiments else LIB
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
@@ -54,13 +58,13 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -11,6 +11,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip.so")
+if os.environ.get("DET6D_EXPERIMENTS_LIB"):      # scripts/experiments only: the -DDET6D_EXPERIMENTS build (de6d_amd/_build.py)
+    LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip_experiments.so")
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 

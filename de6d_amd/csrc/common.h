@@ -24,6 +24,28 @@ static inline int det6d_check_launch(const char *what) {
 
 static inline int det6d_divup(int a, int b) { return (a + b - 1) / b; }
 
+// Environment switches.  Two kinds:
+//  * det6d_switch_*: select between implementations that give IDENTICAL results (the default kernel or an exact
+//    fallback the parity tests also cover: DET6D_FPS_SKIP, DET6D_FPS_CELLS_MIN_N, DET6D_LINEAR_NO_FAST,
+//    DET6D_CHAIN_LDS, DET6D_CHAIN_NO_WIDE).  Always compiled.
+//  * det6d_env_*: tile sweeps, timing hooks and stand-ins used by scripts/experiments.  Compiled to their default
+//    unless the library is built with -DDET6D_EXPERIMENTS (python -m de6d_amd._build --experiments): the shipped
+//    library ignores those variables.
+static inline int det6d_switch_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static inline bool det6d_switch_set(const char *name) { return getenv(name) != nullptr; }
+#ifdef DET6D_EXPERIMENTS
+static inline int det6d_env_int(const char *name, int dflt) { return det6d_switch_int(name, dflt); }
+static inline bool det6d_env_set(const char *name) { return det6d_switch_set(name); }
+#define D6_DBG_IS(v) (dbg == (v))
+#else
+static inline int det6d_env_int(const char *, int dflt) { return dflt; }
+static inline bool det6d_env_set(const char *) { return false; }
+#define D6_DBG_IS(v) false
+#endif
+
 // squared distance with the contraction order documented in oracle/det6d_oracle.c
 __device__ __forceinline__ float d6_sqdist(float dx, float dy, float dz) {
   return D6_FMA(dz, dz, D6_FMA(dx, dx, dy * dy));
@@ -114,7 +136,7 @@ __device__ __forceinline__ void d6_sampler_priority() {
 // reservation is OFF by default; DET6D_FPS_LDS_HOG=<KB left to other workgroups> turns it on.
 template <typename KernelT>
 static inline unsigned det6d_sampler_lds_hog(KernelT kernel, unsigned static_bytes) {
-  static const int keep_kb = getenv("DET6D_FPS_LDS_HOG") ? atoi(getenv("DET6D_FPS_LDS_HOG")) : 0;   // LDS left to others (KB); 0 = no reservation
+  static const int keep_kb = det6d_env_int("DET6D_FPS_LDS_HOG", 0);   // LDS left to others (KB); 0 = no reservation
   if (keep_kb <= 0) return 0u;
   const unsigned total = 160u * 1024u, keep = (unsigned)keep_kb * 1024u;
   if (static_bytes + keep >= total) return 0u;

@@ -226,7 +226,7 @@ static int check_group(int ns, int smin, int *split, const int *cnt, const int *
 
 static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa_in, float *zero_y, int ldy, hipStream_t stream) {
   // experiment knob: DET6D_COMPACT_TOL=t keeps a centre in ONE power-of-two part when that wastes <= 1/t of its rows
-  static const int tol = getenv("DET6D_COMPACT_TOL") ? atoi(getenv("DET6D_COMPACT_TOL")) : 0;
+  static const int tol = det6d_env_int("DET6D_COMPACT_TOL", 0);
   PairArgs pa = pa_in;
   if (tol > 0) { pa.g[0].split |= tol << 8; pa.g[1].split |= tol << 8; }
   const int total = b * m;

@@ -487,7 +487,9 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
                            long long idx_bstride, int idx_add, int init_temp, const float *xyz,
                            const float *temp, int *perm, int *idx, hipStream_t stream);
 
-// ---- profiling stand-ins (DET6D_FPS_STANDIN=1|2, never a result path; scripts/gpu_whatif.py) -------------
+#ifdef DET6D_EXPERIMENTS
+// ---- profiling stand-ins (DET6D_FPS_STANDIN=1|2, never a result path; scripts/experiments/gpu_whatif.py): only in
+// ---- libraries built with -DDET6D_EXPERIMENTS, never in the shipped one
 // Same launch shape and duration as the SA1 sampler (one 512-thread workgroup per scene, ~1.35 us per round)
 // but 1: holds 128 VGPRs and sleeps (register / occupancy footprint only), 2: keeps the vector ALU busy
 // from a small register footprint.  Both write a strided index pattern so that the rest of the pass runs.
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(512) void fps_standin_kernel(int n, int m, int *idx
   for (int j = threadIdx.x; j < m; j += blockDim.x) out[j] = (int)(((long long)j * n) / m) + idx_add + (s == -1.f);
 }
 }  // namespace
+#endif
 
 DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                               const float *scores, float gamma, float *temp, int *idx, int idx_stride,
@@ -533,23 +536,25 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   const float *x = xyz ? xyz + (size_t)lo * 3 : nullptr;
   int *out = idx ? idx + idx_offset : nullptr;
   if (scores) return launch_fps<true>(b, n, m, x, scores + lo, temp, out, vw, (hipStream_t)stream);
-  static const int standin = getenv("DET6D_FPS_STANDIN") ? atoi(getenv("DET6D_FPS_STANDIN")) : 0;
+#ifdef DET6D_EXPERIMENTS
+  static const int standin = det6d_env_int("DET6D_FPS_STANDIN", 0);
   if (standin && n == 16384 && out) {
     if (standin == 1) hipLaunchKernelGGL(fps_standin_kernel<1>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
     else hipLaunchKernelGGL(fps_standin_kernel<2>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
     return det6d_check_launch("det6d_fps_fused(stand-in)");
   }
+#endif
   // Opt-in (DET6D_FPS_CELLS_MIN_N=4096|8192|16384): the exact spatially pruned cell sampler of
   // fps_cells.hip (its Morton permutation lives in `temp`, which is free because the min-distances start
   // at 1e10 implicitly).  Bit-exact, but measured on MI355X at 1.39 us/round for 16384 points against
   // 1.35 for the fat-thread kernel: only ~5 of 256 cells are touched per round, yet the per-round
   // latency chain (box test, per-cell DPP arg-max, two reductions, LDS hand-off, barrier; 0.62 us with
   // zero cells touched) costs what the pruning saves.  Kept off by default until that chain is shorter.
-  static const int cells_min_n = getenv("DET6D_FPS_CELLS_MIN_N") ? atoi(getenv("DET6D_FPS_CELLS_MIN_N")) : (1 << 30);
+  static const int cells_min_n = det6d_switch_int("DET6D_FPS_CELLS_MIN_N", (1 << 30));
   // Default for 16384 points: the wave-skip sampler of fps_cells.hip (Morton-sorted fat threads, one bounding
   // box per wave; 16 waves x 16 points per lane by default, DET6D_FPS_SKIP=8: 8 x 32, =0: the plain fat-thread
   // kernel).  Same picks bit for bit, 0.96 (1.16) vs 1.35 us per round and a fraction of the vector-ALU work.
-  static const int skip_mode = getenv("DET6D_FPS_SKIP") ? atoi(getenv("DET6D_FPS_SKIP")) : 16;
+  static const int skip_mode = det6d_switch_int("DET6D_FPS_SKIP", 16);
   const bool use_cells = n >= cells_min_n && (n == 16384 || n == 8192 || n == 4096);
   if (temp && x && out && b > 0 && m > 0 && (use_cells || (skip_mode && n == 16384)))
     return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, 0, vw.idx_bstride, lo, 1, x, nullptr,

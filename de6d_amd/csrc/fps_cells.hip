@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
       const float gy = fmaxf(0.f, fmaxf(blo_y - cy, cy - bhi_y));
       const float gz = fmaxf(0.f, fmaxf(blo_z - cz, cz - bhi_z));
       const float lb = d6_sqdist(gx, gy, gz);
-      const bool act = lane < CPW && (r == 1 || (!(lb >= M) && dbg != 1));
+      const bool act = lane < CPW && (r == 1 || (!(lb >= M) && !D6_DBG_IS(1)));
       cells = (unsigned)__ballot(act);
     }
     // 2. update them
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int lo
       sl[wave].idx = st.cidx;
       sl[wave].x = st.cbx; sl[wave].y = st.cby; sl[wave].z = st.cbz;
     }
-    if (dbg != 2) __syncthreads();
+    if (!D6_DBG_IS(2)) __syncthreads();
     const int src = lane & (NW - 1);
     const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
     const int i2 = sl[src].idx;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   __shared__ int slot_k[2][NW];
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
-  if (dbg == 9) d6_sampler_priority();   // raised wave priority measured 1 % SLOWER in the pipeline (9668 vs 9750 scenes/s): DET6D_FPS_DBG=9 turns it on
+  if (D6_DBG_IS(9)) d6_sampler_priority();   // raised wave priority measured 1 % SLOWER in the pipeline (9668 vs 9750 scenes/s): DET6D_FPS_DBG=9 turns it on
   xyz += (size_t)blockIdx.x * xyz_bstride;
   perm += (size_t)blockIdx.x * n;
   idxs += (size_t)blockIdx.x * idx_bstride;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
 
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
   if (h == 0) idxs[0] = idx_add;
-  if (dbg == 7 && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x] = wall_clock64();
+  if (D6_DBG_IS(7) && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x] = wall_clock64();
   // cached arg-max of every group of this wave (uniform)
   float cg_val[G], cg_x[G], cg_y[G], cg_z[G];
   int cg_k[G];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
       const float gy = fmaxf(0.f, fmaxf(loy[g] - cy, cy - hiy[g]));
       const float gz = fmaxf(0.f, fmaxf(loz[g] - cz, cz - hiz[g]));
       const float lb = d6_sqdist(gx, gy, gz);
-      if (!(lb >= cg_val[g]) && !(dbg == 3 && r > 1)) {   // wave-uniform branch (dbg 3: fixed per-round cost only)
+      if (!(lb >= cg_val[g]) && !(D6_DBG_IS(3) && r > 1)) {   // wave-uniform branch (dbg 3: fixed per-round cost only)
         float best = -1.0f;
         int bs = 0;
         const f32x2s c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
@@ -419,25 +419,27 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
     cz = d6_readlane_f(z2, ww);
     if (h == 0) idxs[r] = old + idx_add;
   }
-  if (dbg == 7 && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x + 1] = wall_clock64();
+  if (D6_DBG_IS(7) && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 }  // namespace
 
+#ifdef DET6D_EXPERIMENTS
 // timing experiments only: copies the 2 x 64 clock samples of the last DET6D_FPS_DBG=7 sampler launch to the host
 extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsigned long long *out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(d6_fps_clock), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
+#endif
 
 // Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
                            long long idx_bstride, int idx_add, int init_temp, const float *xyz,
                            const float *temp, int *perm, int *idx, hipStream_t stream) {
   dim3 grid(b);
-  static const int dbg = getenv("DET6D_FPS_DBG") ? atoi(getenv("DET6D_FPS_DBG")) : 0;  // timing experiments only
+  static const int dbg = det6d_env_int("DET6D_FPS_DBG", 0);  // timing experiments only
   // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
   // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
-  static const int skip = getenv("DET6D_FPS_SKIP") ? atoi(getenv("DET6D_FPS_SKIP")) : 16;
+  static const int skip = det6d_switch_int("DET6D_FPS_SKIP", 16);
   if (skip && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
     // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two

@@ -583,7 +583,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   // tile choice by the EXPECTED live rows: a compact list is sized for the dense row space (capacity) but holds a
   // fraction of it (DET6D_COMPACT_ROWS_EST = expected capacity / live ratio; the grid still covers the capacity)
-  static const int rows_est_div = getenv("DET6D_COMPACT_ROWS_EST") ? atoi(getenv("DET6D_COMPACT_ROWS_EST")) : 1;
+  static const int rows_est_div = det6d_env_int("DET6D_COMPACT_ROWS_EST", 1);
   const int rows_est = a->hdr && rows_est_div > 1 ? a->rows / rows_est_div : a->rows;
   const int gm = det6d_divup(rows_est, 128);
   const int gm_cap = det6d_divup(a->rows, 128);
@@ -592,7 +592,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
                         : a->mode == DET6D_A_COMPACT ? (size_t)a->n : (size_t)a->rows;
   const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull &&
                       (size_t)a->rows * a->ldy * 4 < 0xfff00000ull;
-  static const bool no_fast = getenv("DET6D_LINEAR_NO_FAST") != nullptr;
+  static const bool no_fast = det6d_switch_set("DET6D_LINEAR_NO_FAST");
   if (!fits32 || no_fast) {   // same tiles, plain predicated loader
     if (a->ncols > 64) {
       if (gm * det6d_divup(a->ncols, 128) < 256)
@@ -615,12 +615,12 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   // compact lists (a->hdr): launches of 7-43 k live rows; 128x64 tiles fill the idle chip better when such a launch runs
   // alone (GEMM family 52 -> 56 TF stand-alone) and are neutral with 16 passes in flight (9930 vs 9920 scenes/s, family
   // at saturation 90.6 vs 90.2 TF), so they are the default there; dense rows keep 128x128
-  static const int k64_env = getenv("DET6D_LINEAR_K64MAX") ? atoi(getenv("DET6D_LINEAR_K64MAX")) : -1;
-  static const int n64_env = getenv("DET6D_LINEAR_N64MAX") ? atoi(getenv("DET6D_LINEAR_N64MAX")) : -1;
+  static const int k64_env = det6d_env_int("DET6D_LINEAR_K64MAX", -1);
+  static const int n64_env = det6d_env_int("DET6D_LINEAR_N64MAX", -1);
   const int force_k_max = k64_env >= 0 ? k64_env : (a->hdr ? 512 : 0);
-  static const bool fast64 = getenv("DET6D_LINEAR_FAST64") ? atoi(getenv("DET6D_LINEAR_FAST64")) != 0 : false;
-  static const bool nbuf2 = getenv("DET6D_LINEAR_NBUF2") != nullptr;   // double-buffered LDS tiles, one barrier per slab
-  static const int bk32 = getenv("DET6D_LINEAR_BK32") ? atoi(getenv("DET6D_LINEAR_BK32")) : 0;   // K from which BK = 32 is used
+  static const bool fast64 = (det6d_env_int("DET6D_LINEAR_FAST64", 0) != 0);
+  static const bool nbuf2 = det6d_env_set("DET6D_LINEAR_NBUF2");   // double-buffered LDS tiles, one barrier per slab
+  static const int bk32 = det6d_env_int("DET6D_LINEAR_BK32", 0);   // K from which BK = 32 is used
   const int force_n_max = n64_env >= 0 ? n64_env : (a->hdr ? 1024 : 512);
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop

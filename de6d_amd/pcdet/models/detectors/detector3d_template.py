@@ -26,6 +26,11 @@ class Detector3DTemplate(nn.Module):
         self.register_buffer('global_step', torch.LongTensor(1).zero_())
         self.module_topology = ['vfe', 'backbone_3d', 'map_to_bev_module', 'pfe', 'backbone_2d', 'dense_head',
                                 'point_head', 'roi_head']
+        # Conv+BN are folded into device matrices at first use.  Any load_state_dict() (also the plain nn.Module one)
+        # drops them; `weights_version` lets captured graphs (runtime.GraphedDet6D), which hold pointers to the folded
+        # tensors, refuse to replay after the weights changed.
+        self.weights_version = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._invalidate_folded())
 
     @property
     def mode(self):
@@ -207,12 +212,14 @@ class Detector3DTemplate(nn.Module):
 
     # ------------------------------------------------------------------ checkpoints
     def _invalidate_folded(self):
+        self.weights_version += 1
         for m in self.modules():
             if hasattr(m, 'invalidate') and m is not self:
                 m.invalidate()
 
     def train(self, mode=True):
-        self._invalidate_folded()
+        if mode != self.training:
+            self._invalidate_folded()
         return super().train(mode)
 
     def _load_state_dict(self, model_state_disk, *, strict=True):

@@ -3,6 +3,7 @@ model from a YAML the way tools/test.py does (core/tools/test.py:21-65), seeded 
 dataset stand-in exposing the attributes Detector3DTemplate.build_networks reads
 (core/pcdet/models/detectors/detector3d_template.py:36-44)."""
 import os
+import time
 
 import numpy as np
 import torch
@@ -207,10 +208,17 @@ class GraphedDet6D(object):
                 self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
         self.count_host = torch.empty(self.count.shape, dtype=self.count.dtype, pin_memory=True)
         self.done = torch.cuda.Event()
+        self._weights_version = getattr(model, 'weights_version', 0)
+
+    def _check_weights(self):
+        if getattr(self.model, 'weights_version', 0) != self._weights_version:
+            raise RuntimeError("the model's weights changed after this pass was captured (load_state_dict / train()): "
+                               "its graph still points at the old folded matrices; build a new GraphedDet6D / Det6DGroup")
 
     def launch_front(self, points=None):
         """segment 0 (everything before the first sampler) on the CURRENT stream (the group's sampler stream), once
         the pass's previous launch has finished with the buffers"""
+        self._check_weights()
         torch.cuda.current_stream().wait_event(self.done)
         if callable(points):          # an input producer filling self.points on the current stream (bench.py pipeline leg)
             points(self)
@@ -229,6 +237,7 @@ class GraphedDet6D(object):
         return self
 
     def launch(self, points=None):
+        self._check_weights()
         with torch.cuda.stream(self.stream):
             if points is not None and points.data_ptr() != self.points.data_ptr():
                 self.points.copy_(points, non_blocking=True)
@@ -239,9 +248,15 @@ class GraphedDet6D(object):
             self.done.record()
         return self
 
+    #: seconds the host spent blocked in finalize() (all passes): host-bound pipelines show ~0 here
+    host_wait_s = 0.0
+
     def finalize(self):
         """pred_dicts of the last launch (views into the graph's static outputs)"""
-        self.done.synchronize()
+        if not self.done.query():
+            t0 = time.perf_counter()
+            self.done.synchronize()
+            GraphedDet6D.host_wait_s += time.perf_counter() - t0
         return [{'pred_boxes': self.boxes[i, :k], 'pred_scores': self.scores[i, :k],
                  'pred_labels': self.labels[i, :k]} for i, k in enumerate(self.count_host.tolist())]
 

@@ -36,6 +36,25 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert lib.det6d_version().startswith(b"det6d-hip gfx950")
 
 
+def exported_symbols(path):
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-2] in ('T', 'W', 'D', 'B'))
+
+
+def test_dynamic_symbol_table_equals_the_header_both_ways(hip_lib):
+    """nothing undeclared is exported (no debug hooks, no experiment entries) and nothing declared is missing"""
+    ours = [s for s in exported_symbols(hip_lib) if not s.startswith(('__hip', '_fini', '_init', '__bss', '_edata', '_end'))]
+    assert ours == declared_symbols(), set(ours) ^ set(declared_symbols())
+
+
+def test_shipped_library_ignores_experiment_variables(hip_lib):
+    """stand-ins / timing hooks / tile sweeps are compiled only with -DDET6D_EXPERIMENTS"""
+    out = subprocess.run(['strings', hip_lib], capture_output=True, text=True).stdout
+    for name in ('DET6D_FPS_STANDIN', 'DET6D_FPS_DBG', 'DET6D_LINEAR_K64MAX', 'DET6D_LINEAR_BK32', 'DET6D_COMPACT_TOL',
+                 'fps_standin_kernel', 'det6d_dbg_fps_clock'):
+        assert name not in out, name
+
+
 def test_code_object_is_gfx950_only(hip_lib):
     out = subprocess.run(['strings', hip_lib], capture_output=True, text=True).stdout
     assert 'gfx950' in out

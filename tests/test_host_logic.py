@@ -100,3 +100,20 @@ def test_training_mode_is_refused():
     model.train()
     with pytest.raises(NotImplementedError):
         model({'batch_size': 1, 'points': torch.zeros((2048, 5))})
+
+
+def test_any_load_state_dict_drops_the_folded_weights():
+    """a plain nn.Module.load_state_dict() must invalidate the folded Conv+BN matrices and bump the version
+    captured graphs check"""
+    from de6d_amd.runtime import load_config, build_model
+    model = build_model(load_config('synthetic_models/det6d_tiny.yaml'), seed=3)
+    sa = model.backbone_3d.SA_modules[0]
+    sa._folded = {'device': 'stale'}
+    model.point_head._folded = {'device': 'stale'}
+    v0 = model.weights_version
+    model.load_state_dict(model.state_dict())          # NOT the private _load_state_dict
+    assert sa._folded is None and model.point_head._folded is None
+    assert model.weights_version > v0
+    v1 = model.weights_version
+    model.eval()                                       # no mode change: nothing to drop
+    assert model.weights_version == v1
