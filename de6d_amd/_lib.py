@@ -67,6 +67,7 @@ _SIGNATURES = {
     "det6d_three_interpolate_grad": [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
     "det6d_boxes_overlap_bev": [c_int, _P, c_int, _P, _P, _P],
     "det6d_boxes_iou_bev": [c_int, _P, c_int, _P, _P, _P],
+    "det6d_boxes_iou_bev_cpu": [c_int, _P, c_int, _P, _P],
     "det6d_nms": [c_int, _P, c_float, _P, _P, _P, _P],
     "det6d_nms_normal": [c_int, _P, c_float, _P, _P, _P, _P],
     "det6d_nms_to_host": [c_int, _P, c_float, _P, c_int, _P],

@@ -44,6 +44,12 @@ def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
 
 
 def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
-    raise NotImplementedError(
-        "boxes_iou_bev_cpu (iou3d_cpu.cpp:232-252) is a host-side helper outside the GPU hot path; "
-        "libdet6d_hip has no CPU code paths by design")
+    """iou3d_cpu.cpp:232-252: CPU float32 tensors (N,7), (M,7) -> ans_iou (N,M) filled in place; returns 1"""
+    for t in (boxes_a, boxes_b, ans_iou):
+        if t.is_cuda or t.dtype != ans_iou.dtype or t.element_size() != 4 or not t.is_contiguous():
+            raise L.Det6dError("boxes_iou_bev_cpu needs contiguous CPU float32 tensors (iou3d_cpu.cpp:237-244)")
+    if tuple(ans_iou.shape) != (boxes_a.shape[0], boxes_b.shape[0]):
+        raise L.Det6dError("ans_iou must be (N, M)")
+    L.call("det6d_boxes_iou_bev_cpu", boxes_a.shape[0], ctypes.c_void_p(boxes_a.data_ptr()), boxes_b.shape[0],
+           ctypes.c_void_p(boxes_b.data_ptr()), ctypes.c_void_p(ans_iou.data_ptr()))
+    return 1

@@ -4,6 +4,21 @@ import torch
 from ...ops_backend import fused, iou3d_nms_hip as iou3d_nms_cuda
 
 
+def boxes_bev_iou_cpu(boxes_a, boxes_b):
+    """(N,7),(M,7) CPU tensors or numpy arrays -> rotated BEV IoU (N,M) of the same kind (iou3d_nms_utils.py:12-29)"""
+    import numpy as np
+    if isinstance(boxes_a, np.ndarray):            # common_utils.check_numpy_to_torch (common_utils.py:15-18): .float()
+        boxes_a = torch.from_numpy(boxes_a).float()
+    is_numpy = isinstance(boxes_b, np.ndarray)     # the reference keeps the flag of boxes_b (iou3d_nms_utils.py:21-22)
+    if is_numpy:
+        boxes_b = torch.from_numpy(boxes_b).float()
+    assert not (boxes_a.is_cuda or boxes_b.is_cuda), 'Only support CPU tensors'
+    assert boxes_a.shape[1] == 7 and boxes_b.shape[1] == 7
+    ans_iou = boxes_a.new_zeros(torch.Size((boxes_a.shape[0], boxes_b.shape[0])))
+    iou3d_nms_cuda.boxes_iou_bev_cpu(boxes_a.contiguous(), boxes_b.contiguous(), ans_iou)
+    return ans_iou.numpy() if is_numpy else ans_iou
+
+
 def boxes_iou_bev(boxes_a, boxes_b):
     """(N,7),(M,7) device tensors -> rotated BEV IoU (N,M)"""
     assert boxes_a.shape[1] == boxes_b.shape[1] == 7

@@ -133,6 +133,12 @@ int det6d_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const fl
 int det6d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                         float *ans_iou, det6d_stream_t stream);
 
+/* Replaces boxes_iou_bev_cpu (iou3d_nms_api.cpp:16, iou3d_cpu.cpp:232-252; Python caller boxes_bev_iou_cpu,
+ * iou3d_nms_utils.py:12-29): the reference runs this entry on the CPU over HOST tensors, and so does this one
+ * (all three pointers are host memory, no stream; same geometry code as the device kernels). */
+int det6d_boxes_iou_bev_cpu(int num_a, const float *boxes_a_host, int num_b, const float *boxes_b_host,
+                            float *ans_iou_host);
+
 /* number of uint64 words the mask scratch of det6d_nms* needs: K * ceil(K/64) */
 int64_t det6d_nms_mask_words(int boxes_num);
 
