@@ -19,6 +19,11 @@ class _LazyCoords(list):
         super().__init__([None] * len(xyz_levels))
         self._xyz = list(xyz_levels)
 
+    def reset(self):
+        """a captured pass was replayed: the centres changed under the cached lists (runtime.GraphedDet6D)"""
+        for i in range(len(self)):
+            list.__setitem__(self, i, None)
+
     def _get(self, i):
         v = list.__getitem__(self, i)
         if v is None:

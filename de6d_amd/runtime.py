@@ -210,6 +210,11 @@ class GraphedDet6D(object):
         self.done = torch.cuda.Event()
         self._weights_version = getattr(model, 'weights_version', 0)
 
+    def _relaunched(self):
+        lazy = self.batch_dict.get('point_coords_list', None)
+        if hasattr(lazy, 'reset'):
+            lazy.reset()           # lists built on first access from the centres: stale after a replay
+
     def _check_weights(self):
         if getattr(self.model, 'weights_version', 0) != self._weights_version:
             raise RuntimeError("the model's weights changed after this pass was captured (load_state_dict / train()): "
@@ -219,6 +224,7 @@ class GraphedDet6D(object):
         """segment 0 (everything before the first sampler) on the CURRENT stream (the group's sampler stream), once
         the pass's previous launch has finished with the buffers"""
         self._check_weights()
+        self._relaunched()
         torch.cuda.current_stream().wait_event(self.done)
         if callable(points):          # an input producer filling self.points on the current stream (bench.py pipeline leg)
             points(self)
@@ -238,6 +244,7 @@ class GraphedDet6D(object):
 
     def launch(self, points=None):
         self._check_weights()
+        self._relaunched()
         with torch.cuda.stream(self.stream):
             if points is not None and points.data_ptr() != self.points.data_ptr():
                 self.points.copy_(points, non_blocking=True)

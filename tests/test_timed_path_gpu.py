@@ -1,0 +1,214 @@
+"""Parity on EXACTLY what bench.py times ("parity on what is timed"): kitti_models/det6d_car.yaml at
+batch 8 x 16384 points through the two-stage pipeline (Det6DGroup of 4 passes: grouped 32-scene first sampler + captured
+graph segments; ScenePipeline around it), on compact rows and on the reference's dense rows, against oracle/model.py bit
+for bit; the sloped and the 65536-point configurations through captured graphs; and the scene-sharded HIP engine on two
+rank processes."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_model_gpu import check, flat_points
+from tests.util import make_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_of(cfg, model, pts_np, b):
+    from oracle import model as omodel
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    return omodel.forward(cfg.MODEL, sd, pts_np, b)
+
+
+def test_bench_group_full_size_vs_oracle(oracle_ops):
+    """the benchmarked shape: Det6DGroup(k=4), batch 8 x 16384, four DIFFERENT batches; every pass against the oracle:
+    sampled points of every level, features, logits, boxes, kept detections and their order — bit-exact"""
+    from de6d_amd.runtime import load_config, build_model, Det6DGroup
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=1234, device='cuda')
+    b, n, k = 8, 16384, 4
+    batches_np = [flat_points(make_batch(7000 + 100 * j, b, n)) for j in range(k)]
+    batches = [torch.from_numpy(p).cuda() for p in batches_np]
+    group = Det6DGroup(model, b, n, k, torch.cuda.Stream(), points=batches,
+                       main_streams=[torch.cuda.Stream() for _ in range(k)])
+    for rep in range(2):                       # the second replay must give the same answer as the first
+        passes = group.launch()
+        preds = [r.finalize() for r in passes]
+    torch.cuda.synchronize()
+    for j in (0, k - 1, 1, 2):                 # first and last pass first
+        ref = oracle_of(cfg, model, batches_np[j], b)
+        check(passes[j].batch_dict, preds[j], ref, b)
+        assert sum(len(p['pred_scores']) for p in preds[j]) > 0
+
+
+def test_bench_group_full_size_dense_rows():
+    """the same test on the reference's dense (centre x nsample) rows: bench.py's `dense_rows` leg
+    (DET6D_DENSE_ROWS is read at import: child process)"""
+    if os.environ.get('DET6D_DENSE_ROWS'):
+        pytest.skip('already the dense-rows child')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                          'test_bench_group_full_size_vs_oracle or test_scene_pipeline'],
+                         env=dict(os.environ, DET6D_DENSE_ROWS='1'), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert 'passed' in out.stdout
+
+
+@pytest.mark.parametrize("cfg_name,b,n,tilt", [('slopedkitti_models/det6d_car.yaml', 8, 16384, True),
+                                               ('synthetic_models/det6d_65536.yaml', 2, 65536, False),
+                                               ('kitti_models/det6d_3class.yaml', 4, 16384, False)])
+def test_other_baseline_configs_through_captured_graphs(oracle_ops, cfg_name, b, n, tilt):
+    """BASELINE configs 3, 5 and 4 (per-GPU share: 32 scenes / 8 GPUs) through GraphedDet6D, replayed twice with two
+    different batches, against the oracle"""
+    from de6d_amd.runtime import load_config, build_model, GraphedDet6D
+    cfg = load_config(cfg_name)
+    model = build_model(cfg, seed=77, device='cuda')
+    runner = GraphedDet6D(model, b, n)
+    for seed in (8100, 8200):
+        pts_np = flat_points(make_batch(seed, b, n, tilt=tilt))
+        preds = runner.launch(torch.from_numpy(pts_np).cuda()).finalize()
+        torch.cuda.synchronize()
+        ref = oracle_of(cfg, model, pts_np, b)
+        check(runner.batch_dict, preds, ref, b)
+    if tilt:
+        assert (ref['batch_box_preds'][:, 7] != 0).any()      # the pitch branch of the ground-aware decoder occurred
+
+
+def test_scene_pipeline_stream_equals_eager(oracle_ops):
+    """ScenePipeline as bench.py drives it (16 main + 6 sampler streams, groups of 4, 4 groups ahead) on the full-size
+    model: a stream of steps whose length is not a multiple of the group size, distinct resident batches, every finalised
+    step compared with the eager model; then the same pipeline fed from the host (the --h2d route)"""
+    from de6d_amd.runtime import load_config, build_model, ScenePipeline
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=1234, device='cuda')
+    b, n = 8, 16384
+    batches = [torch.from_numpy(flat_points(make_batch(9000 + 50 * j, b, n))).cuda() for j in range(3)]
+    with torch.no_grad():
+        eager = [model({'batch_size': b, 'points': p})[0] for p in batches]
+    torch.cuda.synchronize()
+    pipe = ScenePipeline(model, b, n, n_main=16, group=4, prefetch=4, sampler_streams=6, points=batches)
+    which = {id(r): i % len(batches) for i, r in enumerate(pipe.passes)}
+    seen = []
+
+    def on_done(step, r, preds):
+        want = eager[which[id(r)]]
+        for g, e in zip(preds, want):
+            assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+            assert torch.equal(g['pred_labels'], e['pred_labels'])
+        seen.append(step)
+    assert pipe.run(70, on_done=on_done) == 70
+    assert seen == list(range(70))
+    assert pipe.run(3, on_done=on_done) == 3          # shorter than one group
+
+    # host-fed: a callable writes each pass's input on the sampler stream
+    feed_order = []
+
+    def feed(r):
+        j = len(feed_order) % len(batches)
+        feed_order.append(j)
+        r.points.copy_(batches[j], non_blocking=True)
+    pipe2 = ScenePipeline(model, b, n, n_main=8, group=2, prefetch=2, sampler_streams=3, points=None,
+                          main_streams=pipe.main_streams[:8], samplers=pipe.sampler_streams[:3])
+    step_feed = []
+
+    def on_done2(step, r, preds):
+        j = step_feed[step]
+        for g, e in zip(preds, eager[j]):
+            assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+    feed_order.clear()
+    # passes are fed in launch order == step order
+    n_steps = 21
+    step_feed = [i % len(batches) for i in range(n_steps)]
+    assert pipe2.run(n_steps, feed=feed, on_done=on_done2) == n_steps
+
+
+def test_device_iou_equals_host_entry():
+    """det6d_boxes_iou_bev (device) and det6d_boxes_iou_bev_cpu (the host entry of the reference interface) share
+    include/det6d_geom.h: identical bits"""
+    from de6d_amd.ops import iou3d_nms_hip
+    from tests.util import random_boxes
+    a = torch.from_numpy(random_boxes(21, 300))
+    bx = torch.from_numpy(random_boxes(22, 130))
+    host = torch.zeros((300, 130))
+    iou3d_nms_hip.boxes_iou_bev_cpu(a, bx, host)
+    dev = torch.zeros((300, 130), device='cuda')
+    iou3d_nms_hip.boxes_iou_bev_gpu(a.cuda(), bx.cuda(), dev)
+    assert torch.equal(dev.cpu(), host)
+
+
+# ---- two rank processes: the scene-sharded HIP engine ---------------------------------------------------------------
+
+_RANK_SCRIPT = r'''
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ['DET6D_ROOT'])
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+ndev = torch.cuda.device_count()
+torch.cuda.set_device(rank % ndev)
+# one device per rank -> RCCL; ranks sharing a device (1-GPU box) -> gloo carries the (host-side) merge
+dist.init_process_group('nccl' if ndev >= world else 'gloo', rank=rank, world_size=world)
+from de6d_amd import parallel
+from de6d_amd.runtime import load_config, build_model, GraphedDet6D
+from tests.test_model_gpu import flat_points
+from tests.util import make_batch
+cfg = load_config('synthetic_models/det6d_tiny.yaml')
+model = build_model(cfg, seed=3, device='cuda')
+num_scenes, n, b = 11, 2048, 2
+mine = parallel.scene_shard(num_scenes, rank, world)          # DistributedSampler(shuffle=False) order
+runner = GraphedDet6D(model, b, n)
+results = []
+for i in range(0, len(mine), b):
+    ids = mine[i:i + b]
+    while len(ids) < b:
+        ids = ids + [ids[-1]]
+    pts = flat_points(np.stack([make_batch(500 + s, 1, n)[0] for s in ids], 0))
+    preds = runner.launch(torch.from_numpy(pts).cuda()).finalize()
+    for s, p in list(zip(ids, preds))[:len(mine[i:i + b])]:
+        results.append({'scene': s, 'boxes': p['pred_boxes'].cpu().numpy(), 'scores': p['pred_scores'].cpu().numpy()})
+merged = parallel.gather_detections(results, num_scenes)
+if rank == 0:
+    np.savez(os.environ['DET6D_OUT'], order=np.array([m['scene'] for m in merged]),
+             **{'boxes_%d' % m['scene']: m['boxes'] for m in merged}, **{'scores_%d' % m['scene']: m['scores'] for m in merged})
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_hip_engine_scene_sharding(tmp_path, oracle_ops):
+    """core/tools/test.py:137-143 + DistributedSampler(shuffle=False) + merge_results_dist
+    (core/pcdet/datasets/__init__.py:27-70, common_utils.py:212-233): two rank processes run the HIP engine on their
+    scene shard (scene_shard) and merge with gather_detections; the merged list is in scene order and every scene's
+    detections equal the oracle's.  With two or more devices the ranks use one device each over RCCL; on a one-GPU box
+    both ranks share cuda:0 and the host-side merge goes over gloo (the data path has no collective either way)."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out_file = str(tmp_path / 'merged.npz')
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   DET6D_ROOT=ROOT, DET6D_OUT=out_file, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    z = np.load(out_file)
+    np.testing.assert_array_equal(z['order'], np.arange(11))
+    from de6d_amd.runtime import load_config, build_model
+    from oracle import model as omodel
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=3)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    for s in range(11):
+        pts = flat_points(make_batch(500 + s, 1, 2048))
+        ref = omodel.forward(cfg.MODEL, sd, pts, 1)['pred_dicts'][0]
+        np.testing.assert_array_equal(z['boxes_%d' % s], ref['pred_boxes'])
+        np.testing.assert_array_equal(z['scores_%d' % s], ref['pred_scores'])
