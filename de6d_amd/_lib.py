@@ -72,7 +72,7 @@ _SIGNATURES = {
     "det6d_nms_normal": [c_int, _P, c_float, _P, _P, _P, _P],
     "det6d_nms_to_host": [c_int, _P, c_float, _P, c_int, _P],
     "det6d_pack_points": [c_int, c_int, _P, c_int, _P, _P, _P],
-    "det6d_fps_fused": [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_int, c_int, _P],
+    "det6d_fps_fused": [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, _P, c_int, c_int, _P],
     "det6d_gather_centres": [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
     "det6d_with_batch_index": [c_int, c_int, _P, c_int, c_int, _P, _P],
     "det6d_gather_rows": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
@@ -100,7 +100,7 @@ _SIGNATURES = {
 
 #: every symbol include/det6d_ops.h declares (tests/test_boundary.py checks the export table)
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
-                                                  "det6d_postprocess_workspace_bytes",
+                                                  "det6d_postprocess_workspace_bytes", "det6d_fps_fused_workspace_bytes",
                                                   "det6d_ball_query_grid_workspace_bytes",
                                                   "det6d_prepare_points_workspace_bytes",
                                                   "det6d_compact_rows_capacity", "det6d_compact_hdr_ints"])
@@ -129,6 +129,8 @@ def lib():
         handle.det6d_ball_query_grid_workspace_bytes.restype = c_int64
         handle.det6d_prepare_points_workspace_bytes.argtypes = [c_int, c_int]
         handle.det6d_prepare_points_workspace_bytes.restype = c_int64
+        handle.det6d_fps_fused_workspace_bytes.argtypes = [c_int, c_int]
+        handle.det6d_fps_fused_workspace_bytes.restype = c_int64
         handle.det6d_compact_hdr_ints.argtypes = [c_int]
         handle.det6d_compact_hdr_ints.restype = c_int
         handle.det6d_compact_rows_capacity.argtypes = [c_int, c_int]

@@ -519,11 +519,26 @@ __global__ __launch_bounds__(512) void fps_standin_kernel(int n, int m, int *idx
 }  // namespace
 #endif
 
+// fps_coop.hip: register-resident D-FPS of 32768 / 65536-point scenes by cooperating workgroups
+bool det6d_fps_coop_handles(int n);
+long long det6d_fps_coop_workspace_bytes(int b, int n);
+int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                          const float *xyz, void *workspace, int *idx, hipStream_t stream);
+
+DET6D_API long long det6d_fps_fused_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  long long bytes = (long long)b * n * 4;
+  const long long coop = det6d_fps_coop_workspace_bytes(b, n);
+  if (coop > 0 && coop + 256 > bytes) bytes = coop + 256;
+  return bytes;
+}
+
 DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
-                              const float *scores, float gamma, float *temp, int *idx, int idx_stride,
-                              int idx_offset, det6d_stream_t stream) {
+                              const float *scores, float gamma, float *temp, long long temp_bytes, int *idx,
+                              int idx_stride, int idx_offset, det6d_stream_t stream) {
   if (n_total <= 0 || lo < 0 || hi > n_total || hi <= lo || idx_stride < idx_offset + m) return DET6D_EINVAL;
   const int n = hi - lo;
+  if (temp && temp_bytes < (long long)b * n * 4) return DET6D_EINVAL;
   FpsView vw;
   vw.xyz_bstride = (long long)n_total * 3;
   vw.w_bstride = n_total;
@@ -555,6 +570,17 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   // box per wave; 16 waves x 16 points per lane by default, DET6D_FPS_SKIP=8: 8 x 32, =0: the plain fat-thread
   // kernel).  Same picks bit for bit, 0.96 (1.16) vs 1.35 us per round and a fraction of the vector-ALU work.
   static const int skip_mode = det6d_switch_int("DET6D_FPS_SKIP", 16);
+  // 32768 / 65536 points: the scene is held in registers by 2 / 4 cooperating workgroups (fps_coop.hip) when the caller
+  // supplied the workspace det6d_fps_fused_workspace_bytes asks for; otherwise (or DET6D_FPS_COOP=0) the
+  // memory-resident kernel below, 100x slower, same picks
+  static const int coop_on = det6d_switch_int("DET6D_FPS_COOP", 1);
+  if (coop_on && temp && x && out && b > 0 && m > 0 && det6d_fps_coop_handles(n)) {
+    char *ws = reinterpret_cast<char *>(((uintptr_t)temp + 255) & ~(uintptr_t)255);
+    const long long avail = temp_bytes - (ws - reinterpret_cast<char *>(temp));
+    const long long need = det6d_fps_coop_workspace_bytes(b, n);
+    if (need > 0 && avail >= need)
+      return det6d_fps_coop_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo, x, ws, out, (hipStream_t)stream);
+  }
   const bool use_cells = n >= cells_min_n && (n == 16384 || n == 8192 || n == 4096);
   if (temp && x && out && b > 0 && m > 0 && (use_cells || (skip_mode && n == 16384)))
     return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, 0, vw.idx_bstride, lo, 1, x, nullptr,

@@ -45,9 +45,15 @@ def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None):
         ctl.add_sampler(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset)
         return
     if temp is None:
-        temp = torch.empty((b, hi - lo), dtype=torch.float32, device=xyz.device)
+        temp = fps_workspace(b, hi - lo, xyz.device)
     L.call("det6d_fps_fused", b, n_total, lo, hi, m, L.ptr(xyz), L.ptr(scores), float(gamma), L.ptr(temp),
-           L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
+           temp.numel() * temp.element_size(), L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
+
+
+def fps_workspace(b, n, device='cuda'):
+    """scratch of one sampler launch over b scenes of n points (det6d_fps_fused_workspace_bytes: (b, n) floats, more for
+    the cooperative sampler of 32768 / 65536-point scenes)"""
+    return torch.empty((int(L.lib().det6d_fps_fused_workspace_bytes(b, n)),), dtype=torch.uint8, device=device)
 
 
 def gather_centres(xyz, idx, rows_out=None, zero_from=0):

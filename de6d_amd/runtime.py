@@ -290,7 +290,7 @@ class Det6DGroup(object):
         self.rows_all = torch.empty((k * batch_size, n_points, ld), dtype=torch.float32, device=dev)
         self.xyz_all = torch.empty((k * batch_size, n_points, 3), dtype=torch.float32, device=dev)
         self.idx_all = torch.empty((k * batch_size, m1), dtype=torch.int32, device=dev)
-        self.temp_all = torch.empty((k * batch_size, n_points), dtype=torch.float32, device=dev)
+        self.temp_all = fused.fps_workspace(k * batch_size, n_points, dev)
         self.runners = []
         for j in range(k):
             sl = slice(j * batch_size, (j + 1) * batch_size)
@@ -308,7 +308,7 @@ class Det6DGroup(object):
         with torch.cuda.stream(self.hi):
             for r in self.runners[:self._count]:
                 r.launch_front(points)
-            self._fps(self.xyz_all[:nb], 0, self.n_points, self.m1, None, 1.0, self.idx_all[:nb], 0, temp=self.temp_all[:nb])
+            self._fps(self.xyz_all[:nb], 0, self.n_points, self.m1, None, 1.0, self.idx_all[:nb], 0, temp=self.temp_all)
             self._sampled.record(self.hi)
         return self
 

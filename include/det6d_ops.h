@@ -272,10 +272,14 @@ int det6d_pack_points(int total, int cin, const float *points, int ld, float *ro
  * else: samples range [lo, hi) of xyz (B, n_total, 3); `scores` == NULL -> d-fps, otherwise s-fps
  * with weights sigmoid(scores[b, k])**gamma computed in the kernel (scores (B, n_total));
  * min-distances start at 1e10 implicitly; the picks + lo are written to idx[b*idx_stride +
- * idx_offset + j].  temp: (B, hi-lo) 4-byte scratch (min-distances of the memory-resident kernel, or
- * the Morton permutation of the pruned cell sampler used for d-fps on 8192 / 16384 points). */
+ * idx_offset + j].  temp: scratch of temp_bytes bytes, at least (B, hi-lo) x 4 (min-distances of the
+ * memory-resident kernel, or the Morton permutation of the pruned samplers used for d-fps on 8192 /
+ * 16384 points); with det6d_fps_fused_workspace_bytes(B, hi-lo) bytes, d-fps of 32768 / 65536-point scenes
+ * runs register-resident on 2 / 4 cooperating workgroups per scene (csrc/fps_coop.hip) instead of the
+ * memory-resident kernel (same picks, ~100x faster). */
+long long det6d_fps_fused_workspace_bytes(int b, int n);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
-                    float gamma, float *temp, int *idx, int idx_stride, int idx_offset,
+                    float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     det6d_stream_t stream);
 
 /* xyz_out[b,j,:] = xyz[b,idx[b,j],:] and, if rows_out != NULL, the same into columns 0..2 of the next

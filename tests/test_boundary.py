@@ -57,14 +57,17 @@ def test_shipped_library_ignores_experiment_variables(hip_lib):
 
 def test_code_object_is_gfx950_only(hip_lib):
     out = subprocess.run(['strings', hip_lib], capture_output=True, text=True).stdout
-    assert 'gfx950' in out
-    assert 'gfx90a' not in out and 'gfx942' not in out and 'sm_' not in out
+    # the offload bundle's target ids (rocPRIM's host-side architecture NAME table, linked in with the device radix sort
+    # of csrc/fps_coop.hip, also contains strings like "gfx90a": those are not code objects)
+    targets = set(re.findall(r'amdgcn-amd-amdhsa--(gfx[0-9a-f]+)', out))
+    assert targets == {'gfx950'}, targets
+    assert 'sm_' not in out and 'nvptx' not in out
 
 
 def test_oracle_exports_mirror_the_abi(oracle_ops):
     lib = oracle_ops.lib()
     for name in declared_symbols():
-        if name in ('det6d_version', 'det6d_last_error', 'det6d_nms_to_host', 'det6d_boxes_iou_bev_cpu'):
+        if name in ('det6d_version', 'det6d_last_error', 'det6d_nms_to_host', 'det6d_boxes_iou_bev_cpu', 'det6d_fps_fused_workspace_bytes'):
             continue
         assert hasattr(lib, name.replace('det6d_', 'det6d_oracle_', 1)), name
 

@@ -336,7 +336,7 @@ def test_pruned_fps_kernels_are_exact(skip):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DET6D_FPS_CELLS_MIN_N="4096", DET6D_FPS_SKIP=skip)
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fps_cells.py")], env=env,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_cells.py")], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "exact" in l]
@@ -349,10 +349,24 @@ def test_skip_sampler_on_adversarial_clouds():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fps_stress.py")], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_stress.py")], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout, out.stdout
+
+
+def test_cooperative_sampler_for_large_scenes():
+    """csrc/fps_coop.hip: D-FPS of 32768 / 65536-point scenes held in registers by 2 / 4 cooperating workgroups per scene
+    (BASELINE config 5): the oracle's picks bit for bit, ties / duplicates / odd batch sizes included; and the
+    memory-resident fallback (DET6D_FPS_COOP=0) still agrees"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py")], capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALL True" in out.stdout, out.stdout
+    print(out.stdout)
 
 
 def test_ball_query_grid_adversarial(ext, oracle_ops):
