@@ -321,9 +321,10 @@ def child_rate(args, env_extra, extra_args=(), note=""):
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res = {"scenes_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-               "selfcheck": d.get("selfcheck"), "cold_scenes_per_s": d.get("cold", {}).get("scenes_per_s")}
-        if "compact_fill" in d:
-            res["compact_fill"] = d["compact_fill"]
+               "selfcheck": d.get("selfcheck"), "cold_scenes_per_s": d.get("cold", {}).get("scenes_per_s"),
+               "latency_ms_per_batch": d.get("latency", {}).get("ms_per_batch")}
+        if d.get("compact_fill"):
+            res["compact_fill"] = {g["group"]: g["fill"] for g in d["compact_fill"]}
         if note:
             res["note"] = note
         return res
@@ -638,6 +639,20 @@ def main():
             line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
                                             note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
                                                  "the bound for clouds whose every ball is full")
+        if world == 1 and not args.no_legs and os.environ.get('DET6D_DENSE_ROWS') is None:
+            # the other BASELINE.json configurations (per-GPU share) and ray-cast 64-ring LiDAR scenes, same engine, same
+            # steps / warmup / timing; parity of each: tests/test_timed_path_gpu.py, tests/test_model_gpu.py
+            legs = [
+                ("configs[2] SlopedKITTI Car, batch 8 (sloped scenes, ground-aware pitch branch)",
+                 ['--cfg', 'slopedkitti_models/det6d_car.yaml', '--tilt']),
+                ("configs[3] KITTI 3-class, batch 32 over 8 GPUs = 4 scenes per GPU per step",
+                 ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4']),
+                ("configs[4] 65536 points per scene, batch 64 over 8 GPUs = 8 scenes per GPU per step",
+                 ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8']),
+                ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
+                ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
+            ]
+            line["other_configs"] = {name: child_rate(args, {}, extra) for name, extra in legs}
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

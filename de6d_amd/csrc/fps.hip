@@ -525,6 +525,16 @@ long long det6d_fps_coop_workspace_bytes(int b, int n);
 int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream);
 
+int det6d_fps_coop_status(int b, int n, const void *workspace, hipStream_t stream);
+
+DET6D_API int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream) {
+  if (!temp || !det6d_fps_coop_handles(n)) return DET6D_OK;     // only the cooperative sampler can fail after its launch
+  const char *ws = reinterpret_cast<const char *>(((uintptr_t)temp + 255) & ~(uintptr_t)255);
+  const long long need = det6d_fps_coop_workspace_bytes(b, n);
+  if (need <= 0 || temp_bytes - (ws - reinterpret_cast<const char *>(temp)) < need) return DET6D_OK;
+  return det6d_fps_coop_status(b, n, ws, (hipStream_t)stream);
+}
+
 DET6D_API long long det6d_fps_fused_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
   long long bytes = (long long)b * n * 4;

@@ -20,7 +20,7 @@
 //   order), tags are round numbers >= 1.
 // Placement: block ids of one scene are congruent mod 8, i.e. on one XCD under round-robin dispatch (speed only).
 // A part that waits longer than ~2 s for a partner (it can only be a scheduling accident) raises the error word of
-// the workspace and leaves; the launch then fails loudly in det6d_fps_coop_status instead of hanging the GPU.
+// the workspace and leaves: det6d_fps_fused_status reports the launch as failed instead of the GPU hanging.
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -174,6 +174,32 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
 
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];      // the first pick is point 0 (sampling_gpu.cu:131-133)
   if (part == 0 && h == 0) idxs[0] = idx_add;
+  // Round 0 of the exchange: every part publishes the XCD it runs on (agent-scope words, valid wherever the parts sit).
+  // If all parts share one XCD — the placement the block numbering aims for — later rounds publish with plain
+  // (workgroup-scope) stores that STAY in that XCD's L2, where the partners' L1-bypassing loads find them at L2-hit
+  // latency; agent-scope stores are written through to the fabric and dropped from L2, so every poll would pay a
+  // memory-side round trip.  Parts on different XCDs keep the agent-scope stores.
+  bool same_xcd;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;          // hwreg(HW_REG_XCC_ID, 0, 4)
+    unsigned long long *mine0 = exch + (size_t)part * kSlotWords + 5;               // word 5 of the parity-0 slot
+    if (h == 0) __hip_atomic_store(mine0, co_pack(xcc, 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool reader0 = lane < PARTS;
+    const unsigned long long *theirs0 = exch + (size_t)(reader0 ? lane : 0) * kSlotWords + 5;
+    unsigned long long w0 = 0ull;
+    int spins0 = 0;
+    for (;;) {
+      w0 = __hip_atomic_load(theirs0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = !reader0 || (unsigned)(w0 >> 32) == 0x7fffffffu;
+      if (__ballot(!ok) == 0ull) break;
+      if (++spins0 > (1 << 22)) {
+        if (lane == 0) atomicExch(err, 1);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    same_xcd = __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;
+  }
   float cg_val = __builtin_inff(), cg_x = 0.f, cg_y = 0.f, cg_z = 0.f;
   int cg_k = 0;
 
@@ -237,7 +263,8 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
       const unsigned payload = lane == 0 ? __builtin_bit_cast(unsigned, bmax) : lane == 1 ? (unsigned)pk
                                : lane == 2 ? __builtin_bit_cast(unsigned, pxw) : lane == 3 ? __builtin_bit_cast(unsigned, pyw)
                                                                                            : __builtin_bit_cast(unsigned, pzw);
-      __hip_atomic_store(mine + lane, co_pack(payload, (unsigned)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (same_xcd) __hip_atomic_store(mine + lane, co_pack(payload, (unsigned)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(mine + lane, co_pack(payload, (unsigned)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // lane 5 * p + w reads word w of part p
     const int rp = lane / 5, rw = lane - 5 * rp;
@@ -347,4 +374,19 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
     hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
                        vals_out, idx, exch, err);
   return det6d_check_launch("det6d_fps (cooperative)");
+}
+
+// error word of the last cooperative launch on `workspace` (synchronises `stream`): 0 = fine
+int det6d_fps_coop_status(int b, int n, const void *workspace, hipStream_t stream) {
+  if (!det6d_fps_coop_handles(n) || b <= 0 || b > 4096 || !workspace) return DET6D_EINVAL;
+  const CoopLayout L = coop_layout(b, n);
+  int flag = 0;
+  if (hipMemcpyAsync(&flag, (const char *)workspace + L.err, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return DET6D_ELAUNCH;
+  if (flag) {
+    det6d_set_error("det6d_fps (cooperative): a workgroup waited > 2 s for its partners", hipErrorLaunchFailure);
+    return DET6D_ELAUNCH;
+  }
+  return DET6D_OK;
 }

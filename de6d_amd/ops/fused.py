@@ -50,6 +50,11 @@ def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None):
            temp.numel() * temp.element_size(), L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
 
 
+def fps_status(b, n, temp):
+    """raises if the last cooperative sampler launch on `temp` gave up (synchronises the current stream)"""
+    L.call("det6d_fps_fused_status", b, n, L.ptr(temp), temp.numel() * temp.element_size(), L.stream_ptr())
+
+
 def fps_workspace(b, n, device='cuda'):
     """scratch of one sampler launch over b scenes of n points (det6d_fps_fused_workspace_bytes: (b, n) floats, more for
     the cooperative sampler of 32768 / 65536-point scenes)"""

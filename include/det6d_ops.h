@@ -278,6 +278,10 @@ int det6d_pack_points(int total, int cin, const float *points, int ld, float *ro
  * runs register-resident on 2 / 4 cooperating workgroups per scene (csrc/fps_coop.hip) instead of the
  * memory-resident kernel (same picks, ~100x faster). */
 long long det6d_fps_fused_workspace_bytes(int b, int n);
+/* After a det6d_fps_fused launch of b scenes of n = hi-lo points on `temp`: synchronises `stream` and returns DET6D_OK, or
+ * DET6D_ELAUNCH when a workgroup of the cooperative sampler gave up waiting for its partners (the picks are then
+ * invalid; it cannot happen unless the GPU refuses to co-schedule 4 workgroups for seconds).  Blocks: not capturable. */
+int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     det6d_stream_t stream);

@@ -11,10 +11,12 @@ oops.build()
 def check(xyz, m, tag):
     x = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
     idx = torch.full((xyz.shape[0], m), -7, dtype=torch.int32, device='cuda')
-    fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0); torch.cuda.synchronize()
+    ws = fused.fps_workspace(xyz.shape[0], xyz.shape[1])
+    fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0, temp=ws); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0); torch.cuda.synchronize()
+    fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0, temp=ws); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fused.fps_status(xyz.shape[0], xyz.shape[1], ws)
     ok = np.array_equal(idx.cpu().numpy(), oops.fps(xyz, m))
     print(tag, 'exact', ok, '%.2f ms, %.2f us/round' % (dt * 1e3, dt * 1e6 / max(m - 1, 1)), flush=True)
     return ok

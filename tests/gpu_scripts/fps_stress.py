@@ -1,6 +1,6 @@
 """extra seeds / cloud shapes for the wave-skip sampler against the CPU oracle (bit-exact indices)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from de6d_amd.ops import fused
 from oracle import ops as oops
