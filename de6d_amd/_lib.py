@@ -73,8 +73,8 @@ _SIGNATURES = {
     "det6d_nms_to_host": [c_int, _P, c_float, _P, c_int, _P],
     "det6d_pack_points": [c_int, c_int, _P, c_int, _P, _P, _P],
     "det6d_fps_fused_status": [c_int, c_int, _P, c_int64, _P],
-    "det6d_fps_fused": [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, _P, c_int, c_int, _P],
-    "det6d_gather_centres": [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
+    "det6d_fps_fused": [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, _P, c_int, c_int, c_int, _P],
+    "det6d_gather_centres": [c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P],
     "det6d_with_batch_index": [c_int, c_int, _P, c_int, c_int, _P, _P],
     "det6d_gather_rows": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_linear": [ctypes.POINTER(LinearArgs), _P],

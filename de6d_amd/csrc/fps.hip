@@ -545,7 +545,7 @@ DET6D_API long long det6d_fps_fused_workspace_bytes(int b, int n) {
 
 DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                               const float *scores, float gamma, float *temp, long long temp_bytes, int *idx,
-                              int idx_stride, int idx_offset, det6d_stream_t stream) {
+                              int idx_stride, int idx_offset, int idx_bias, det6d_stream_t stream) {
   if (n_total <= 0 || lo < 0 || hi > n_total || hi <= lo || idx_stride < idx_offset + m) return DET6D_EINVAL;
   const int n = hi - lo;
   if (temp && temp_bytes < (long long)b * n * 4) return DET6D_EINVAL;
@@ -554,7 +554,7 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   vw.w_bstride = n_total;
   vw.temp_bstride = n;
   vw.idx_bstride = idx_stride;
-  vw.idx_add = lo;
+  vw.idx_add = lo + idx_bias;
   vw.init_temp = 1;
   vw.w_is_score = 1;
   vw.gamma = gamma;
@@ -564,8 +564,8 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
 #ifdef DET6D_EXPERIMENTS
   static const int standin = det6d_env_int("DET6D_FPS_STANDIN", 0);
   if (standin && n == 16384 && out) {
-    if (standin == 1) hipLaunchKernelGGL(fps_standin_kernel<1>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
-    else hipLaunchKernelGGL(fps_standin_kernel<2>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo);
+    if (standin == 1) hipLaunchKernelGGL(fps_standin_kernel<1>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo + idx_bias);
+    else hipLaunchKernelGGL(fps_standin_kernel<2>, dim3(b), dim3(512), 0, (hipStream_t)stream, n, m, out, idx_stride, lo + idx_bias);
     return det6d_check_launch("det6d_fps_fused(stand-in)");
   }
 #endif
@@ -589,11 +589,11 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
     const long long avail = temp_bytes - (ws - reinterpret_cast<char *>(temp));
     const long long need = det6d_fps_coop_workspace_bytes(b, n);
     if (need > 0 && avail >= need)
-      return det6d_fps_coop_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo, x, ws, out, (hipStream_t)stream);
+      return det6d_fps_coop_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x, ws, out, (hipStream_t)stream);
   }
   const bool use_cells = n >= cells_min_n && (n == 16384 || n == 8192 || n == 4096);
   if (temp && x && out && b > 0 && m > 0 && (use_cells || (skip_mode && n == 16384)))
-    return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, 0, vw.idx_bstride, lo, 1, x, nullptr,
+    return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, 0, vw.idx_bstride, lo + idx_bias, 1, x, nullptr,
                                   reinterpret_cast<int *>(temp), out, (hipStream_t)stream);
   return launch_fps<false>(b, n, m, x, nullptr, temp, out, vw, (hipStream_t)stream);
 }

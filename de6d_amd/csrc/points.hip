@@ -158,7 +158,7 @@ __global__ void pack_points_kernel(int64_t total, int width, int ld, const float
 
 // centres of a layer: xyz_out[b,j,:] = xyz[b,idx[b,j],:]; optionally the same three columns into the
 // next level's row buffer, whose padding columns [zero_from, ld_rows) are cleared here as well
-__global__ void gather_centres_kernel(int64_t total, int n, int m, int ld_rows, int zero_from,
+__global__ void gather_centres_kernel(int64_t total, int n, int m, int idx_stride, int idx_bias, int ld_rows, int zero_from,
                                       const float *__restrict__ xyz, const int *__restrict__ idx,
                                       float *__restrict__ xyz_out, float *__restrict__ rows_out) {
   const int per = 3 + (rows_out ? ld_rows - zero_from : 0);
@@ -167,7 +167,7 @@ __global__ void gather_centres_kernel(int64_t total, int n, int m, int ld_rows, 
     const int64_t bj = i / per;
     if (c < 3) {
       const int64_t bi = bj / m;
-      const float v = xyz[(bi * n + idx[bj]) * 3 + c];
+      const float v = xyz[(bi * n + idx[bi * idx_stride + (bj - bi * m)] + idx_bias) * 3 + c];
       xyz_out[bj * 3 + c] = v;
       if (rows_out) rows_out[bj * ld_rows + c] = v;
     } else {
@@ -339,14 +339,14 @@ DET6D_API int det6d_pack_points(int total, int cin, const float *points, int ld,
   return det6d_check_launch("det6d_pack_points");
 }
 
-DET6D_API int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, float *xyz_out,
-                                   float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream) {
-  if (b < 0 || n <= 0 || m < 0 || !xyz || !idx || !xyz_out) return DET6D_EINVAL;
+DET6D_API int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, int idx_stride, int idx_bias,
+                                   float *xyz_out, float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || !xyz || !idx || !xyz_out || idx_stride < m) return DET6D_EINVAL;
   if (rows_out && (ld_rows < 3 || zero_from < 3 || zero_from > ld_rows)) return DET6D_EINVAL;
   const int per = 3 + (rows_out ? ld_rows - zero_from : 0);
   const int64_t total = (int64_t)b * m * per;
   if (total == 0) return DET6D_OK;
-  hipLaunchKernelGGL(gather_centres_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, n, m, ld_rows,
+  hipLaunchKernelGGL(gather_centres_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, n, m, idx_stride, idx_bias, ld_rows,
                      zero_from, xyz, idx, xyz_out, rows_out);
   return det6d_check_launch("det6d_gather_centres");
 }

@@ -30,24 +30,20 @@ def pack_points(points, ld):
     return rows, xyz
 
 
-#: capture controller of runtime.GraphedDet6D (a pass of a Det6DGroup): while it is recording, sampler calls are not
-#: launched but handed to it (the group launches the first sampler of all its passes between their graph segments)
+#: capture controller of runtime.GraphedDet6D (a pass of a Det6DGroup): the SA layers ask it which of their samplers the
+#: group launches for all its passes ahead of the captured segments (runtime.hoist_plan) and where their picks live
 SAMPLER_SEGMENTS = None
 
 
-def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None):
+def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None, idx_bias=0):
     """one sampler of an SA layer: range slice, sigmoid**gamma weights, 1e10 init, +lo offset and the
     write into the concatenated index buffer all happen inside the kernel"""
     L.require_cuda(xyz, scores, idx_out)
     b, n_total, _ = xyz.shape
-    ctl = SAMPLER_SEGMENTS
-    if ctl is not None and ctl.recording:
-        ctl.add_sampler(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset)
-        return
     if temp is None:
         temp = fps_workspace(b, hi - lo, xyz.device)
     L.call("det6d_fps_fused", b, n_total, lo, hi, m, L.ptr(xyz), L.ptr(scores), float(gamma), L.ptr(temp),
-           temp.numel() * temp.element_size(), L.ptr(idx_out), idx_out.shape[1], idx_offset, L.stream_ptr())
+           temp.numel() * temp.element_size(), L.ptr(idx_out), idx_out.shape[1], idx_offset, idx_bias, L.stream_ptr())
 
 
 def fps_status(b, n, temp):
@@ -61,13 +57,17 @@ def fps_workspace(b, n, device='cuda'):
     return torch.empty((int(L.lib().det6d_fps_fused_workspace_bytes(b, n)),), dtype=torch.uint8, device=device)
 
 
-def gather_centres(xyz, idx, rows_out=None, zero_from=0):
-    L.require_cuda(xyz, idx, rows_out)
+def gather_centres(xyz, idx, rows_out=None, zero_from=0, out=None, idx_bias=0):
+    """idx may be a column slice of a wider (b, M) index buffer (row stride M)"""
+    L.require_cuda(xyz, rows_out, out)
+    if not idx.is_cuda or idx.stride(1) != 1:
+        raise L.Det6dError("gather_centres: idx must be a device tensor with unit column stride")
     b, n, _ = xyz.shape
     m = idx.shape[1]
-    out = torch.empty((b, m, 3), dtype=torch.float32, device=xyz.device)
-    L.call("det6d_gather_centres", b, n, m, L.ptr(xyz), L.ptr(idx), L.ptr(out), L.ptr(rows_out),
-           rows_out.shape[-1] if rows_out is not None else 0, zero_from, L.stream_ptr())
+    if out is None:
+        out = torch.empty((b, m, 3), dtype=torch.float32, device=xyz.device)
+    L.call("det6d_gather_centres", b, n, m, L.ptr(xyz), L.ptr(idx), idx.stride(0) if b > 1 else max(idx.stride(0), m), idx_bias, L.ptr(out),
+           L.ptr(rows_out), rows_out.shape[-1] if rows_out is not None else 0, zero_from, L.stream_ptr())
     return out
 
 

@@ -172,17 +172,16 @@ class _PointnetSAModuleFSBase(nn.Module):
         jobs = list(zip(self.sample_range_list, self.sample_method_list, self.npoint_list))
         b = xyz.shape[0]
         ctl = fused.SAMPLER_SEGMENTS if (len(jobs) == 1 or SEQUENTIAL_SAMPLERS) else None   # segmented graph capture (runtime.py)
-        idx = ctl.sample_index_buffer(b, sum(self.npoint_list)) if ctl is not None else None
+        layer = ctl.next_layer() if ctl is not None else -1
+        idx = ctl.index_buffer(layer, b, sum(self.npoint_list)) if ctl is not None else None
         if idx is None:
             idx = torch.empty((b, sum(self.npoint_list)), dtype=torch.int32, device=xyz.device)
         offsets = [sum(self.npoint_list[:i]) for i in range(len(jobs))]
         if len(jobs) == 1 or SEQUENTIAL_SAMPLERS:
-            if ctl is not None:
-                ctl.enter_samplers()
-            for ((lo, hi), method, npoint), off in zip(jobs, offsets):
+            for j, (((lo, hi), method, npoint), off) in enumerate(zip(jobs, offsets)):
+                if ctl is not None and ctl.hoisted(layer, j):
+                    continue          # launched by the group for all its passes, ahead of this segment (runtime.hoist_plan)
                 self._sample_one(xyz, scores, lo, hi, method, npoint, idx, off)
-            if ctl is not None:
-                ctl.exit_samplers()
             return idx
         main = torch.cuda.current_stream()
         if self._side_streams is None or len(self._side_streams) < len(jobs) - 1:

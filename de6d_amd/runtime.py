@@ -95,19 +95,55 @@ def mlp_flops_per_scene(model, n_points):
 SAMPLER_GROUP = 4   # passes per group in bench.py (--group)
 
 
+def hoist_plan(sa_modules, n_points):
+    """Which samplers of the backbone depend on NOTHING but the input cloud?  The first layer's d-fps does, and so does
+    every later d-fps whose range lies inside the picks of such a sampler of the layer before (Det6D: 4096 of the input
+    -> d-fps 512 of those 4096 -> d-fps 256 of those 512; the s-fps halves need the confidence scores of the layer
+    before).  Returns the launch list of a group's stage 1, in order:
+      dict(layer, j, src=(layer-1, j') | None, lo, hi (relative to src), m, offset (column in the layer's index buffer),
+           bias (added to every pick on top of lo: start of src inside the previous layer's output), feeds=bool)"""
+    plan, outs = [], {}
+    n_in = n_points
+    for layer, sa in enumerate(sa_modules):
+        jobs = list(zip(sa.sample_range_list, sa.sample_method_list, sa.npoint_list))
+        offsets = [sum(sa.npoint_list[:i]) for i in range(len(jobs))]
+        for j, ((lo, hi), method, npoint) in enumerate(jobs):
+            hi = n_in if hi == -1 else hi
+            if method != 'd-fps':
+                continue
+            if layer == 0:
+                if not (len(jobs) == 1 and lo == 0 and hi == n_in):
+                    raise NotImplementedError("grouped first sampler: expected one d-fps over the whole input cloud")
+                plan.append(dict(layer=0, j=0, src=None, lo=0, hi=n_in, m=npoint, offset=0, bias=0, feeds=False))
+                outs[(0, 0)] = (0, npoint)
+                continue
+            for (pl, pj), (poff, pn) in list(outs.items()):
+                if pl == layer - 1 and poff <= lo and hi <= poff + pn:
+                    plan.append(dict(layer=layer, j=j, src=(pl, pj), lo=lo - poff, hi=hi - poff, m=npoint, offset=offsets[j],
+                                     bias=poff, feeds=False))
+                    outs[(layer, j)] = (offsets[j], npoint)
+                    break
+        n_in = sum(sa.npoint_list)
+    for step in plan:
+        if step['src'] is not None:
+            for other in plan:
+                if (other['layer'], other['j']) == step['src']:
+                    other['feeds'] = True
+    return plan
+
+
 class _SegmentCapture(object):
-    """capture controller: graph segments on `main`; the first sampler is left to the group (whose `front` buffers the
-    pass packs its input into and reads the sampled indices from), later samplers stay inside the graph"""
+    """capture controller of a pass that belongs to a Det6DGroup: graph segments on `main`, cut where the first SA layer
+    samples (the group launches its hoisted samplers for all its passes between segment 0 = pack and the rest); the SA
+    layers take their index buffers from the group and skip the samplers the group launches (`front`)."""
 
     def __init__(self, main, pool, front):
         self.main, self.pool = main, pool
-        self.front = front
-        self.segments = []          # [graph, ...]
-        self.recording = False
-        self.pack_out = (front[0], front[1])
+        self.front = front               # dict(rows, xyz, idx={layer: (B, M) slice}, hoisted={(layer, j)})
+        self.segments = []               # [graph, ...]
+        self.pack_out = (front['rows'], front['xyz'])
         self._graph = self._ctx = None
-        self._n_sample = 0
-        self._cut = False
+        self._layer = -1
 
     def begin(self):
         self._graph = torch.cuda.CUDAGraph()
@@ -121,35 +157,21 @@ class _SegmentCapture(object):
         self.segments.append(self._graph)
         self._graph = self._ctx = None
 
-    def sample_index_buffer(self, b, m):
-        """index buffer of the next _sample call: the group's for the first sampler, None = allocate as usual"""
-        if self._n_sample == 0:
-            assert tuple(self.front[2].shape) == (b, m)
-            return self.front[2]
-        return None
+    def next_layer(self):
+        self._layer += 1
+        if self._layer == 0:             # segment 0 ends here; the group's stage 1 runs between the segments
+            self.end()
+            self.begin()
+        return self._layer
 
-    def enter_samplers(self):
-        self._n_sample += 1
-        self._cut = self._n_sample == 1
-        if not self._cut:
-            return
-        self._graph.capture_end()          # segment 0 ends here; the group launches the sampler between the segments
-        self._ctx.__exit__(None, None, None)
-        self.recording = True
+    def index_buffer(self, layer, b, m):
+        buf = self.front['idx'].get(layer)
+        if buf is not None:
+            assert tuple(buf.shape) == (b, m)
+        return buf
 
-    def add_sampler(self, xyz, lo, hi, m, scores, gamma, idx_out, idx_offset):
-        # launched by the group for all its passes at once: must be the plain input-only D-FPS
-        if not (scores is None and lo == 0 and hi == xyz.shape[1] and idx_offset == 0 and m == idx_out.shape[1]
-                and xyz.data_ptr() == self.front[1].data_ptr() and idx_out.data_ptr() == self.front[2].data_ptr()):
-            raise NotImplementedError("grouped first sampler: expected one d-fps over the whole input cloud")
-
-    def exit_samplers(self):
-        if not self._cut:
-            return
-        self._cut = False
-        self.recording = False
-        self.segments.append(self._graph)
-        self.begin()
+    def hoisted(self, layer, j):
+        return (layer, j) in self.front['hoisted']
 
 
 class GraphedDet6D(object):
@@ -161,8 +183,8 @@ class GraphedDet6D(object):
     to have it copied in first, or write into `self.points` yourself."""
 
     def __init__(self, model, batch_size, n_points, point_width=5, points=None, warmup=2, front=None, stream=None):
-        """front = (rows, xyz, idx) slices of a Det6DGroup: the pass packs its points into them and takes the first
-        sampler's indices from idx (the group launches that sampler for all its passes)"""
+        """front = dict(rows, xyz, idx, hoisted) of a Det6DGroup: the pass packs its points into the group's slices and
+        takes the picks of the hoisted samplers from the group's index buffers (the group launches them for all its passes)"""
         from .ops import fused
         self.model = model
         self.batch_size = batch_size
@@ -269,11 +291,11 @@ class GraphedDet6D(object):
 
 
 class Det6DGroup(object):
-    """K captured passes whose FIRST sampler (D-FPS over the input cloud: depends on nothing else) runs as one
-    launch over all K x B scenes on a stream of its own; see SAMPLER_GROUP above.  Two stages:
-      launch_front(): pack + first sampler of the K passes on `sampler_stream` (waits until the passes' previous
+    """K captured passes whose INPUT-ONLY samplers (hoist_plan: the first layer's D-FPS and the d-fps chain below it, which
+    depend on nothing but the input cloud) run as one launch each over all K x B scenes on a stream of its own.  Two stages:
+      launch_front(): pack + the hoisted samplers of the K passes on `sampler_stream` (waits until the passes' previous
                       launch is done with the buffers);
-      launch_rest():  the remaining graph segments of every pass on its main stream, after the sampler.
+      launch_rest():  the remaining graph segments of every pass on its main stream, after the samplers.
     Issue launch_front() of later groups BEFORE launch_rest() of earlier ones and the samplers (one 1024-thread
     workgroup per scene, a 3.5 ms latency chain that waits 10-20 ms for a free CU beside GEMM traffic) run ahead of
     the GEMM stage instead of blocking its streams.  launch() = both stages back to back."""
@@ -281,34 +303,55 @@ class Det6DGroup(object):
     def __init__(self, model, batch_size, n_points, k, sampler_stream, point_width=5, points=None, main_streams=None):
         from .ops import fused
         from .pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import rows_ld
-        sa1 = model.backbone_3d.SA_modules[0]
-        m1 = sum(sa1.npoint_list)
+        sa_modules = list(model.backbone_3d.SA_modules)
         ld = rows_ld(point_width - 4)
         dev = 'cuda'
-        self.k, self.batch_size, self.n_points, self.m1 = k, batch_size, n_points, m1
+        nb = k * batch_size
+        self.k, self.batch_size, self.n_points = k, batch_size, n_points
         self.hi = sampler_stream
-        self.rows_all = torch.empty((k * batch_size, n_points, ld), dtype=torch.float32, device=dev)
-        self.xyz_all = torch.empty((k * batch_size, n_points, 3), dtype=torch.float32, device=dev)
-        self.idx_all = torch.empty((k * batch_size, m1), dtype=torch.int32, device=dev)
-        self.temp_all = fused.fps_workspace(k * batch_size, n_points, dev)
+        self.plan = hoist_plan(sa_modules, n_points)
+        if os.environ.get('DET6D_NO_HOIST'):          # only the first layer's sampler ahead of the passes (round-1 behaviour)
+            self.plan = self.plan[:1]
+            self.plan[0]['feeds'] = False
+        self.rows_all = torch.empty((nb, n_points, ld), dtype=torch.float32, device=dev)
+        self.xyz_all = torch.empty((nb, n_points, 3), dtype=torch.float32, device=dev)
+        self.idx_all, self.ctr_all, self.ws = {}, {}, {}
+        for step in self.plan:
+            layer = step['layer']
+            if layer not in self.idx_all:
+                self.idx_all[layer] = torch.empty((nb, sum(sa_modules[layer].npoint_list)), dtype=torch.int32, device=dev)
+            if step['feeds']:
+                self.ctr_all[(layer, step['j'])] = torch.empty((nb, step['m'], 3), dtype=torch.float32, device=dev)
+            self.ws[(layer, step['j'])] = fused.fps_workspace(nb, step['hi'] - step['lo'], dev)
+        hoisted = {(s['layer'], s['j']) for s in self.plan}
         self.runners = []
         for j in range(k):
             sl = slice(j * batch_size, (j + 1) * batch_size)
             own = points[j % len(points)] if isinstance(points, (list, tuple)) else points   # a static input per pass
-            self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=own,
-                                             front=(self.rows_all[sl], self.xyz_all[sl], self.idx_all[sl]),
+            front = dict(rows=self.rows_all[sl], xyz=self.xyz_all[sl], idx={l: t[sl] for l, t in self.idx_all.items()},
+                         hoisted=hoisted)
+            self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=own, front=front,
                                              stream=None if main_streams is None else main_streams[j % len(main_streams)]))
-        self._fps = fused.fps_fused
+        self._fused = fused
         self._sampled = torch.cuda.Event()
         self._count = k
 
     def launch_front(self, points=None, count=None):
         self._count = self.k if count is None else count
         nb = self._count * self.batch_size
+        F = self._fused
         with torch.cuda.stream(self.hi):
             for r in self.runners[:self._count]:
                 r.launch_front(points)
-            self._fps(self.xyz_all[:nb], 0, self.n_points, self.m1, None, 1.0, self.idx_all[:nb], 0, temp=self.temp_all)
+            for step in self.plan:
+                key = (step['layer'], step['j'])
+                src = self.xyz_all[:nb] if step['src'] is None else self.ctr_all[step['src']][:nb]
+                idx = self.idx_all[step['layer']]
+                F.fps_fused(src, step['lo'], step['hi'], step['m'], None, 1.0, idx[:nb], step['offset'], temp=self.ws[key],
+                            idx_bias=step['bias'])
+                if step['feeds']:     # xyz of these picks: the cloud the next layer's hoisted sampler works on
+                    F.gather_centres(src, idx[:nb, step['offset']:step['offset'] + step['m']], out=self.ctr_all[key][:nb],
+                                     idx_bias=-step['bias'])
             self._sampled.record(self.hi)
         return self
 

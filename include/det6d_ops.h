@@ -284,12 +284,13 @@ long long det6d_fps_fused_workspace_bytes(int b, int n);
 int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
-                    det6d_stream_t stream);
+                    int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */
 
-/* xyz_out[b,j,:] = xyz[b,idx[b,j],:] and, if rows_out != NULL, the same into columns 0..2 of the next
+/* xyz_out[b,j,:] = xyz[b, idx[b*idx_stride + j] + idx_bias, :] (idx_stride >= m: the picks of one sampler inside a
+ * layer's concatenated index buffer; idx_bias: `xyz` holds a sub-range of the cloud the indices refer to) and, if rows_out != NULL, the same into columns 0..2 of the next
  * level's rows (B,m,ld_rows) while clearing its padding columns [zero_from, ld_rows). */
-int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, float *xyz_out,
-                         float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream);
+int det6d_gather_centres(int b, int n, int m, const float *xyz, const int *idx, int idx_stride, int idx_bias,
+                         float *xyz_out, float *rows_out, int ld_rows, int zero_from, det6d_stream_t stream);
 
 /* dst (b*m, 1+ncol) = [batch index, src[b,j,0:ncol]] — the reference's `point_coords`-style tensors
  * (pointnet2_backbone.py:236-240,257-261). */

@@ -117,3 +117,15 @@ def test_any_load_state_dict_drops_the_folded_weights():
     v1 = model.weights_version
     model.eval()                                       # no mode change: nothing to drop
     assert model.weights_version == v1
+
+
+def test_hoist_plan_is_the_input_only_sampler_chain():
+    """runtime.hoist_plan: Det6D's d-fps chain (4096 of the input -> 512 of those -> 256 of those) depends on nothing but
+    the input cloud; the s-fps halves (confidence-weighted) do not"""
+    from de6d_amd.runtime import load_config, build_model, hoist_plan
+    model = build_model(load_config('kitti_models/det6d_car.yaml'), seed=1)
+    plan = hoist_plan(list(model.backbone_3d.SA_modules), 16384)
+    assert [(s['layer'], s['j'], s['src'], s['lo'], s['hi'], s['m'], s['offset'], s['bias'], s['feeds']) for s in plan] == [
+        (0, 0, None, 0, 16384, 4096, 0, 0, True),
+        (1, 1, (0, 0), 0, 4096, 512, 512, 0, True),
+        (2, 1, (1, 1), 0, 512, 256, 256, 512, False)]
