@@ -85,6 +85,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   const int ar = tid >> 2, akq = tid & 3;
   const float *arow[NA];
   float csub[NA][3];
+  // gathered rows [x - cx, y - cy, z - cz, f..]: the chain takes the feature columns first and the three relative
+  // coordinates LAST (the oracle's chain_k): slab 0 carries zeros in their place, a closing 4-deep slab adds them
+  const bool rot = g.mode != DET6D_A_ROWS && g.k > 3;
+  float rel[NA][3];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) rel[i][0] = rel[i][1] = rel[i][2] = 0.f;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int r = row0 + ar + 64 * i;
@@ -169,6 +175,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         }
         if (k0 == 0 && akq == 0 && u == 0) {  // grouped_xyz -= new_xyz (pointnet2_utils.py:449-450)
           v.x = v.x - csub[i][0]; v.y = v.y - csub[i][1]; v.z = v.z - csub[i][2];
+          if (rot) {   // the relative coordinates enter the chain LAST (oracle: chain_k): kept for the closing mini-slab
+            rel[i][0] = v.x; rel[i][1] = v.y; rel[i][2] = v.z;
+            v.x = v.y = v.z = 0.f;
+          }
         }
         ra[i][u] = v;
       }
@@ -298,6 +308,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         ra[i][0].x = ra[i][0].x - csub[i][0]; ra[i][0].y = ra[i][0].y - csub[i][1]; ra[i][0].z = ra[i][0].z - csub[i][2];
+        if (rot) {
+          rel[i][0] = ra[i][0].x; rel[i][1] = ra[i][0].y; rel[i][2] = ra[i][0].z;
+          ra[i][0].x = ra[i][0].y = ra[i][0].z = 0.f;
+        }
       }
     }
   } else {
@@ -349,6 +363,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
       buf ^= 1;
     }
     if (k0 < K) compute_tail(buf, K - k0);
+  }
+
+  if (rot) {   // closing slab: k = 0, 1, 2 of the gathered rows (relative coordinates) x weight rows 0..2
+    __syncthreads();
+    if (akq == 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        float *dst = As_all + ar + 64 * i;
+        dst[0 * LDA_S] = rel[i][0]; dst[1 * LDA_S] = rel[i][1]; dst[2 * LDA_S] = rel[i][2]; dst[3 * LDA_S] = 0.f;
+      }
+    }
+    if (tid < BN) {
+      const int c = colb + tid;
+      const bool ok = c < g.ldw;
+      Bs_all[0 * BN + tid] = ok ? g.w[c] : 0.f;
+      Bs_all[1 * BN + tid] = ok ? g.w[(size_t)g.ldw + c] : 0.f;
+      Bs_all[2 * BN + tid] = ok ? g.w[(size_t)2 * g.ldw + c] : 0.f;
+      Bs_all[3 * BN + tid] = 0.f;
+    }
+    __syncthreads();
+    kstep(As_all, Bs_all, 0);
+    kstep(As_all, Bs_all, 1);
   }
 
   // ---- epilogue ----

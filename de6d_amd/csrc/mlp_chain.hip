@@ -93,6 +93,10 @@ __device__ __forceinline__ void compact_pool(float (&v)[4], int s) {
 
 __device__ __forceinline__ float relu1(float v) { return v > 0.f ? v : 0.f; }
 
+// column of a gathered row [x - cx, y - cy, z - cz, f_0 ..] at position j of the oracle's fma chain (chain_k in
+// oracle/det6d_oracle.c): the feature columns first, the three relative coordinates last
+__host__ __device__ __forceinline__ int chain_col(int j, int k1) { return j + 3 < k1 ? j + 3 : j + 3 - k1; }
+
 __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const ChainArgs g) {
   __shared__ float W1[kMaxK1 * kMaxC];
   __shared__ float W2[kMaxC * kMaxC];
@@ -104,9 +108,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
   const int l31 = lane & 31, kh = lane >> 5;
 
   // ---- stage weights (zero padded to the tile widths) ----
+  // layer 1 takes the gathered row in the oracle's chain order (chain_k): feature columns first, relative coordinates last
   for (int t = tid; t < kMaxK1 * kMaxC; t += blockDim.x) {
     const int k = t / kMaxC, c = t % kMaxC;
-    W1[t] = (k < g.k1 && c < g.c1) ? g.w1[(size_t)k * g.ldw1 + c] : 0.f;
+    W1[t] = (k < g.k1 && c < g.c1) ? g.w1[(size_t)chain_col(k, g.k1) * g.ldw1 + c] : 0.f;
   }
   for (int t = tid; t < kMaxC * kMaxC; t += blockDim.x) {
     const int k = t / kMaxC, c = t % kMaxC;
@@ -143,6 +148,13 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
         const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
         av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
       }
+    }
+    {
+      float t8[kMaxK1];
+#pragma unroll
+      for (int k = 0; k < kMaxK1; ++k) t8[k] = av[k];
+      if (g.k1 == 4) { av[0] = t8[3]; av[1] = t8[0]; av[2] = t8[1]; av[3] = t8[2]; }
+      else { av[0] = t8[3]; av[1] = t8[4]; av[2] = t8[5]; av[3] = t8[6]; av[4] = t8[7]; av[5] = t8[0]; av[6] = t8[1]; av[7] = t8[2]; }
     }
     f32x16 acc;
 #pragma unroll
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   // weight fragments: lane (channel / column = l31, k = 2s + kh); one more step per transposed layer for the shift
   float wf1[S1 + 1], wf2[S2 + 1], wf3[NT3][S3];
 #pragma unroll
-  for (int s = 0; s < S1; ++s) wf1[s] = l31 < C1 ? g.w1[(size_t)(2 * s + kh) * g.ldw1 + l31] : 0.f;
+  for (int s = 0; s < S1; ++s) wf1[s] = l31 < C1 ? g.w1[(size_t)chain_col(2 * s + kh, 4) * g.ldw1 + l31] : 0.f;   // rows 3,0 | 1,2
   wf1[S1] = (kh == 0 && l31 < C1) ? g.s1[l31] : 0.f;
 #pragma unroll
   for (int s = 0; s < S2; ++s) wf2[s] = l31 < C2 ? g.w2[(size_t)(2 * s + kh) * g.ldw2 + l31] : 0.f;
@@ -357,8 +369,8 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[0], kh ? x1 : x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[1], kh ? x3 : x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[0], kh ? x0 : x3, acc, 0, 0, 0);   // chain order: f, dx, dy, dz
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[1], kh ? x2 : x1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[2], one_k0, acc, 0, 0, 0);
     float frag[16];   // frag[s] = activation fragment of k-step s: {half0: channel 2s, half1: channel 2s + 1}
     auto to_fragments = [&](const f32x16 &a, int nreg) {
@@ -470,19 +482,19 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     pk_end = base + wpw * T < live ? base + wpw * T : live;
   }
   // staging with 16-byte loads (all leading dimensions and widths are multiples of 4)
-  auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols) {
+  auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols, bool chain_order) {
     const int c4 = cols / 4;
     for (int t = tid; t < (k_rows + (shift ? 2 : 0)) * c4; t += blockDim.x) {
       const int k = t / c4, c = 4 * (t % c4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < k_rows) v = *reinterpret_cast<const float4 *>(w + (size_t)k * ldw + c);
+      if (k < k_rows) v = *reinterpret_cast<const float4 *>(w + (size_t)(chain_order ? chain_col(k, k_rows) : k) * ldw + c);
       else if (k == k_rows) v = *reinterpret_cast<const float4 *>(shift + c);
       *reinterpret_cast<float4 *>(dst + k * cols + c) = v;
     }
   };
-  stage(W1, g.w1, g.ldw1, g.s1, K1, C1);
-  stage(W2, g.w2, g.ldw2, g.s2, C1, C2);
-  stage(W3, g.w3, g.ldw3, nullptr, C2, C3);
+  stage(W1, g.w1, g.ldw1, g.s1, K1, C1, true);    // layer 1 in the oracle's chain order: features, then dx, dy, dz
+  stage(W2, g.w2, g.ldw2, g.s2, C1, C2, false);
+  stage(W3, g.w3, g.ldw3, nullptr, C2, C3, false);
   float sh3[T3];
 #pragma unroll
   for (int j = 0; j < T3; ++j) sh3[j] = g.s3[32 * j + l31];
@@ -504,13 +516,16 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   auto fetch = [&](int t) {   // t wave-uniform
     if (COMPACT) {
       const int p = g.crow_p[t * 32 + l31];
-      const float *src = g.a + (size_t)p * K1 + kh;
+      const float *row = g.a + (size_t)p * K1;
+      const float *src = row + 3 + kh;          // chain position j = 2s + kh reads column j + 3 (features) ...
 #pragma unroll
-      for (int s = 0; s < S1; ++s) xin[s] = src[2 * s];
+      for (int s = 0; s < S1 - 2; ++s) xin[s] = src[2 * s];
+      xin[S1 - 2] = row[kh ? 0 : K1 - 1];       // ... then (pad, x) and (y, z): chain_col(64..67, 68) = 67, 0, 1, 2
+      xin[S1 - 1] = row[kh ? 2 : 1];
       const int cj = g.crow_c[t * 32 + l31];
       const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
-      csub0 = kh ? c[1] : c[0];
-      csub1 = kh ? 0.f : c[2];
+      csub0 = kh ? c[0] : 0.f;
+      csub1 = kh ? c[2] : c[1];
       cnt0 = cnt1 = 0;
       const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
 #pragma unroll
@@ -524,12 +539,15 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     const int bi = c0 / g.m;
     const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
     const int p = g.idx[t * 32 + l31];
-    const float *src = g.a + ((size_t)bi * g.n + p) * K1 + kh;
+    const float *row = g.a + ((size_t)bi * g.n + p) * K1;
+    const float *src = row + 3 + kh;
 #pragma unroll
-    for (int s = 0; s < S1; ++s) xin[s] = src[2 * s];
+    for (int s = 0; s < S1 - 2; ++s) xin[s] = src[2 * s];
+    xin[S1 - 2] = row[kh ? 0 : K1 - 1];
+    xin[S1 - 1] = row[kh ? 2 : 1];
     const float *c = g.ctr + (size_t)cj * g.ldctr;
-    csub0 = kh ? c[1] : c[0];         // k = 0 / 1
-    csub1 = kh ? 0.f : c[2];          // k = 2 / 3 (the feature column is not shifted)
+    csub0 = kh ? c[0] : 0.f;          // chain positions 64 | 65: pad | x
+    csub1 = kh ? c[2] : c[1];         // chain positions 66 | 67: y | z
     cnt0 = g.cnt[c0];
     cnt1 = NS == 32 ? 0 : g.cnt[c0 + 1];
   };
@@ -572,8 +590,8 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     int my_oc[4];
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) my_oc[qq] = oc_n[qq];
-    xin[0] = xin[0] - csub0;
-    xin[1] = xin[1] - csub1;
+    xin[S1 - 2] = xin[S1 - 2] - csub0;     // pad | dx
+    xin[S1 - 1] = xin[S1 - 1] - csub1;     // dy | dz
     // ---- layer 1 (transposed): K1 -> C1 ----
     float f1[S2];
 #pragma unroll

@@ -602,6 +602,17 @@ ORACLE_API int det6d_oracle_compact_groups_pair(int b, int n, int m, int smin, i
                                      crow_c_b, zero_y, ldy, col0_b, width_b);
 }
 
+/* Order of the fma chain of one output.  Plain rows: k ascending.  GATHERED rows [x - cx, y - cy, z - cz, f_0 ..] (the first
+ * layer of a grouped MLP): the feature columns first (k = 3 .. K-1), the three relative coordinates LAST.  The reference's
+ * Conv2d over torch.cat([grouped_xyz, grouped_features]) (pointnet2_utils.py:449-455, pointnet2_modules.py:561-568) is a
+ * cuDNN / ATen GEMM whose summation order is unspecified, so any fixed order restates it; this one makes the feature part
+ * of the chain a function of the POINT alone, which the HIP path computes once per point instead of once per
+ * (centre, neighbour) row (csrc/expand.hip).  Pinned like every other order: tests/golden/det6d_tiny.npz, 1e-4 abs. */
+static inline int chain_k(int kk, int K, int gathered) {
+  if (!gathered || K <= 3) return kk;
+  return kk + 3 < K ? kk + 3 : kk + 3 - K;
+}
+
 /* det6d_linear over a compact row list: rows = hdr[0]; mode 2 gathers through crow_p / crow_c; pool = -1 takes the
  * maximum over the rows of every centre (empty balls -> 0): a centre in ONE part overwrites y, a centre cut into
  * several parts is max-combined with what y holds (the caller zeroes it), like the kernels' atomic max. */
@@ -623,7 +634,8 @@ static int oracle_linear_compact(const det6d_linear_args *g) {
       for (int k = 0; k < K; ++k) arow[k] = src[k];
     }
     for (int c = 0; c < N; ++c) acc[c] = 0.f;
-    for (int k = 0; k < K; ++k) {
+    for (int kk = 0; kk < K; ++kk) {
+      const int k = chain_k(kk, K, g->mode == 2);
       const float av = arow[k];
       const float *wr = g->w + (size_t)k * g->ldw;
       for (int c = 0; c < N; ++c) acc[c] = D6_FMA(av, wr[c], acc[c]);
@@ -681,7 +693,8 @@ ORACLE_API int det6d_oracle_linear(const det6d_linear_args *g) {
           for (int k = 0; k < K; ++k) arow[k] = src[k];
         }
         for (int c = 0; c < N; ++c) acc[c] = 0.f;
-        for (int k = 0; k < K; ++k) {
+        for (int kk = 0; kk < K; ++kk) {
+          const int k = chain_k(kk, K, g->mode == 1);
           const float av = arow[k];
           const float *wr = g->w + (size_t)k * g->ldw;
           for (int c = 0; c < N; ++c) acc[c] = D6_FMA(av, wr[c], acc[c]);
