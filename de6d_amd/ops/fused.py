@@ -198,6 +198,22 @@ def linear(a, w, shift, act, out, k=None, ncols=None, col0=0, idx=None, ctr=None
     return out
 
 
+def group_expand(p, pcol0, w, shift, act, c1, rows_pts, ctr, out, idx=None, compact=None):
+    """first layer of a grouped MLP from the per-point partial sums P (csrc/expand.hip): out[r, :c1] for every grouped row
+    (dense: idx (B, m, ns); compact: CompactRows), pad columns of `out` zero-filled"""
+    L.require_cuda(p, w, shift, rows_pts, ctr, out, idx)
+    if compact is not None:
+        L.call("det6d_group_expand", compact.capacity, c1, L.ptr(p), p.shape[-1], pcol0, L.ptr(w), w.shape[1], L.ptr(shift), act,
+               L.ptr(rows_pts), rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1], None, 0, 0, 0, L.ptr(compact.hdr),
+               L.ptr(compact.crow_p), L.ptr(compact.crow_c), L.ptr(out), out.shape[-1], L.stream_ptr())
+    else:
+        b, m, ns = idx.shape
+        L.call("det6d_group_expand", b * m * ns, c1, L.ptr(p), p.shape[-1], pcol0, L.ptr(w), w.shape[1], L.ptr(shift), act,
+               L.ptr(rows_pts), rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1], L.ptr(idx), rows_pts.shape[1], m, ns, None, None,
+               None, L.ptr(out), out.shape[-1], L.stream_ptr())
+    return out
+
+
 def sigmoid_pow(scores, gamma, out=None):
     L.require_cuda(scores)
     out = torch.empty_like(scores) if out is None else out

@@ -109,6 +109,11 @@ SEQUENTIAL_SAMPLERS = os.environ.get('DET6D_FORKED_SAMPLERS') is None
 #: dense (B, m, nsample) row space.
 COMPACT_ROWS = os.environ.get('DET6D_DENSE_ROWS') is None
 
+#: First layer of a grouped MLP from per-point partial sums (csrc/expand.hip): one plain GEMM over the N points of the
+#: layer + 3 FMAs per grouped output instead of a (3 + C)-deep GEMM over every (centre, neighbour) row; identical bits
+#: (the chain order of gathered rows puts the relative coordinates last).  DET6D_NO_EXPAND=1: the gathered GEMM instead.
+EXPAND_FIRST_LAYER = os.environ.get('DET6D_NO_EXPAND') is None
+
 
 class _PointnetSAModuleFSBase(nn.Module):
     def __init__(self):
@@ -147,8 +152,23 @@ class _PointnetSAModuleFSBase(nn.Module):
             out_channels = agg[-1][2]
         if self.confidence_mlp is not None:
             conf = to_device(fold_sequential(self.confidence_mlp, rows_ld(out_channels), k_offset=3), device)
+        # groups whose first layer runs as "per-point GEMM + expand" (not the ones a fused chain kernel takes whole)
+        expand, pcols, col = [], {}, 0
+        for gi, (layers, ns) in enumerate(zip(groups, self.nsamples)):
+            if COMPACT_ROWS and ns in (4, 8, 16, 32):
+                chained = fused.chain_compact_eligible(in_ld, layers)
+            else:
+                chained = fused.chain_eligible(in_ld, layers, ns)
+            if EXPAND_FIRST_LAYER and not chained and len(layers) >= 2 and layers[0][2] % 4 == 0 and in_ld > 4:
+                expand.append(gi)
+                pcols[gi] = col
+                col += layers[0][0].shape[1]
+        p_w = None
+        if expand:
+            p_w = torch.cat([groups[gi][0][0] for gi in expand], dim=1).clone()
+            p_w[:3] = 0           # the coordinate rows enter in the expand step; P is the chain over the feature columns
         self._folded = dict(device=device, groups=groups, pooled_width=pooled_width, agg=agg, conf=conf,
-                            out_channels=out_channels)
+                            out_channels=out_channels, expand=expand, pcols=pcols, p_w=p_w)
         return self._folded
 
     # ---- sampling -----------------------------------------------------------------------
@@ -247,7 +267,11 @@ class _PointnetSAModuleFSBase(nn.Module):
                 and (widths[0] | widths[1] | pooled.shape[1]) % 4 == 0):
             # both groups' lists in one pair of launches; their slices of `pooled` are cleared by the builder
             lists = fused.compact_groups_pair(found, n, pooled, [(0, widths[0]), (widths[0], widths[1])])
-        for (idx_cnt, idx), nsample, layers, cr in zip(found, self.nsamples, f['groups'], lists):
+        p_all = None
+        if f['expand']:   # per-point partial sums of the first layers of all expand groups: one plain GEMM over the points
+            p_all = torch.empty((b * n, f['p_w'].shape[1]), dtype=torch.float32, device=rows.device)
+            fused.linear(rows.view(b * n, rows.shape[-1]), f['p_w'], None, 0, p_all)
+        for gi, ((idx_cnt, idx), nsample, layers, cr) in enumerate(zip(found, self.nsamples, f['groups'], lists)):
             if COMPACT_ROWS and nsample in (4, 8, 16, 32):
                 # parts of a centre are combined by an atomic max: the group's slice of `pooled` is cleared by the list builder
                 w_out = layers[-1][2]
@@ -270,7 +294,9 @@ class _PointnetSAModuleFSBase(nn.Module):
                     else:
                         tgt = torch.empty((cr.capacity, w.shape[1]), dtype=torch.float32, device=rows.device)
                         kw = dict(ncols=cout, ncols_pad=w.shape[1] if w.shape[1] != cout else 0)
-                    if li == 0:
+                    if li == 0 and gi in f['expand']:
+                        fused.group_expand(p_all, f['pcols'][gi], w, shift, act, cout, rows, new_xyz, tgt, compact=cr)
+                    elif li == 0:
                         fused.linear(rows, w, shift, act, tgt, ctr=new_xyz, compact=cr, gather=True, **kw)
                     else:
                         fused.linear(x, w, shift, act, tgt, compact=cr, **kw)
@@ -290,7 +316,9 @@ class _PointnetSAModuleFSBase(nn.Module):
                 else:
                     tgt = torch.empty((b * m * nsample, w.shape[1]), dtype=torch.float32, device=rows.device)
                     kw = dict(ncols=cout, ncols_pad=w.shape[1] if w.shape[1] != cout else 0)
-                if li == 0:
+                if li == 0 and gi in f['expand'] and not last:
+                    fused.group_expand(p_all, f['pcols'][gi], w, shift, act, cout, rows, new_xyz, tgt, idx=idx)
+                elif li == 0:
                     fused.linear(rows, w, shift, act, tgt, idx=idx, ctr=new_xyz, **kw)
                 else:
                     fused.linear(x, w, shift, act, tgt, **kw)

@@ -286,6 +286,19 @@ int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */
 
+/* First layer of a grouped MLP from per-point partial sums (csrc/expand.hip): with the chain order of gathered rows
+ * (feature columns first, relative coordinates last) the feature part P[p][c] = chain_{k >= 3}(row_p[k] * W[k][c]) is one
+ * plain det6d_linear over the points (weights with rows 0..2 zeroed, no shift, no activation), and
+ *   out[r][0..c1) = act( fma(dz, W[2], fma(dy, W[1], fma(dx, W[0], P[p(r)][pcol0 ..]))) + shift ),  [c1, ldo) zero,
+ * for every grouped row r: dense rows (idx (B,m,ns) over n points per scene; hdr == NULL) or a compact row list
+ * (hdr / crow_p / crow_c of det6d_compact_groups; rows = capacity, alignment rows zero-filled).  Bit for bit
+ * det6d_linear in the gathered modes.  Replaces grouping_operation + cat + the first Conv2d/BN/ReLU of
+ * pointnet2_utils.py:449-455 / pointnet2_modules.py:561-568 at 3 FMAs per output instead of 3 + C. */
+int det6d_group_expand(int rows, int c1, const float *p, int ldp, int pcol0, const float *w, int ldw,
+                       const float *shift, int act, const float *pts, int ldpts, const float *ctr, int ldctr,
+                       const int *idx, int n, int m, int ns, const int *hdr, const int *crow_p, const int *crow_c,
+                       float *out, int ldo, det6d_stream_t stream);
+
 /* xyz_out[b,j,:] = xyz[b, idx[b*idx_stride + j] + idx_bias, :] (idx_stride >= m: the picks of one sampler inside a
  * layer's concatenated index buffer; idx_bias: `xyz` holds a sub-range of the cloud the indices refer to) and, if rows_out != NULL, the same into columns 0..2 of the next
  * level's rows (B,m,ld_rows) while clearing its padding columns [zero_from, ld_rows). */

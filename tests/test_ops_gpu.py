@@ -355,6 +355,52 @@ def test_skip_sampler_on_adversarial_clouds():
     assert "ALL True" in out.stdout, out.stdout
 
 
+@pytest.mark.parametrize("lda,c1", [(68, 64), (132, 128), (260, 256), (8, 32)])
+def test_group_expand_equals_the_gathered_first_layer(ext, oracle_ops, lda, c1):
+    """csrc/expand.hip: per-point partial sums (one plain GEMM over the points, coordinate rows zeroed) + three FMAs per
+    grouped output == the oracle's first layer over the gathered rows (feature columns first, relative coordinates
+    last), dense rows and compact lists, bit for bit"""
+    fused = ext[2]
+    rng = np.random.default_rng(lda)
+    b, n, m, ns = 2, 700, 96, 16
+    rows = rng.normal(size=(b, n, lda)).astype(np.float32)
+    rows[..., lda - 1] = 0.0                                    # pad column
+    ctr = np.ascontiguousarray(rows[:, :m, :3] + rng.normal(size=(b, m, 3)).astype(np.float32) * 0.1)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    w = (rng.normal(size=(lda, c1)) * 0.2).astype(np.float32)
+    w[lda - 1] = 0.0
+    shift = rng.normal(size=(c1,)).astype(np.float32)
+    ref = oracle_ops.linear(rows, w, shift, 1, idx=idx, ctr=ctr)
+    wz = w.copy(); wz[:3] = 0.0
+    p = torch.empty((b * n, c1), device='cuda')
+    fused.linear(dev(rows).view(b * n, lda), dev(wz), None, 0, p)
+    out = torch.full((b * m * ns, c1 + 4), 7.0, device='cuda')
+    fused.group_expand(p, 0, dev(w), dev(shift), 1, c1, dev(rows), dev(ctr), out, idx=dev(idx))
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :c1], ref)
+    assert (got[:, c1:] == 0).all()
+    # the gathered GEMM of det6d_linear follows the same chain order
+    y = torch.empty((b * m * ns, c1), device='cuda')
+    fused.linear(dev(rows), dev(w), dev(shift), 1, y, idx=dev(idx), ctr=dev(ctr))
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    # compact list of the same neighbourhoods: every live row equals the dense row it stands for
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    for bi in range(b):
+        for j in range(m):
+            c = max(int(cnt[bi, j]), 1)
+            idx[bi, j] = np.resize(idx[bi, j, :c], ns)            # cyclic padding like the ball query's
+    cr = fused.compact_groups(dev(cnt), dev(idx), n)
+    outc = torch.full((cr.capacity, c1), 5.0, device='cuda')
+    fused.group_expand(p, 0, dev(w), dev(shift), 1, c1, dev(rows), dev(ctr), outc, compact=cr)
+    yc = torch.empty((cr.capacity, c1), device='cuda')
+    fused.linear(dev(rows), dev(w), dev(shift), 1, yc, ctr=dev(ctr), compact=cr, gather=True)
+    live = int(cr.hdr[0].item())
+    tags = cr.crow_c[:live].cpu().numpy()
+    a, bb = outc[:live].cpu().numpy(), yc[:live].cpu().numpy()
+    np.testing.assert_array_equal(a[tags >= 0], bb[tags >= 0])
+    assert (a[tags < 0] == 0).all()
+
+
 def test_cooperative_sampler_for_large_scenes():
     """csrc/fps_coop.hip: D-FPS of 32768 / 65536-point scenes held in registers by 2 / 4 cooperating workgroups per scene
     (BASELINE config 5): the oracle's picks bit for bit, ties / duplicates / odd batch sizes included; and the
