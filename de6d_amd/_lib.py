@@ -85,6 +85,9 @@ _SIGNATURES = {
     "det6d_compact_groups_pair": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P,
                                   _P, c_int, c_int, _P, c_int, _P],
     "det6d_compact_groups": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "det6d_mlp_group3_supported": [c_int, c_int, c_int, c_int, c_int],
+    "det6d_mlp_group3": [c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
+                         _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "det6d_group_expand": [c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
                            _P, _P, _P, _P, c_int, _P],
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],

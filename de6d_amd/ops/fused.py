@@ -214,6 +214,46 @@ def group_expand(p, pcol0, w, shift, act, c1, rows_pts, ctr, out, idx=None, comp
     return out
 
 
+#: wide grouped MLPs as one launch (csrc/mlp_group.hip); DET6D_NO_GROUP_KERNEL=1: expand + two GEMM launches
+GROUP_KERNEL = os.environ.get('DET6D_NO_GROUP_KERNEL') is None
+
+
+def group_kernel_eligible(layers, ns, compact):
+    if not GROUP_KERNEL or len(layers) != 3 or not all(l[3] == 1 for l in layers):
+        return False
+    return bool(L.lib().det6d_mlp_group3_supported(layers[0][2], layers[1][2], layers[2][2], ns, 1 if compact else 0))
+
+
+def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, compact=None):
+    """expand + layer 2 + layer 3 + pool of a wide radius group in one launch"""
+    L.require_cuda(p, rows_pts, ctr, out, idx, cnt)
+    (w1, s1, c1, _), (w2, s2, c2, _), (w3, s3, c3, _) = layers
+    if compact is not None:
+        rows, hdr = compact.capacity, compact.hdr
+        tail = (None, 0, 0, 0, None, L.ptr(compact.hdr), L.ptr(compact.crow_p), L.ptr(compact.crow_c))
+    else:
+        b, m, ns = idx.shape
+        rows, hdr = b * m * ns, b * m * ns
+        tail = (L.ptr(idx), rows_pts.shape[1], m, ns, L.ptr(cnt), None, None, None)
+
+    def issue(ptr_of=None):
+        y = L.ptr(out) if ptr_of is None else ctypes.c_void_p(ptr_of(out))
+        L.call("det6d_mlp_group3", rows, L.ptr(p), p.shape[-1], pcol0, L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
+               L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, L.ptr(rows_pts), rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1],
+               *tail, y, out.shape[-1], col0, L.stream_ptr())
+    ev = None
+    if LINEAR_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if LINEAR_REPLAY is not None:
+        LINEAR_REPLAY.append((issue, out, (p, layers, rows_pts, ctr, out, idx, cnt, compact)))
+    issue()
+    if ev is not None:
+        ev[1].record()
+        LINEAR_EVENTS.append((ev[0], ev[1], hdr, 1, c1 * c2 + c2 * c3))
+    return out
+
+
 def sigmoid_pow(scores, gamma, out=None):
     L.require_cuda(scores)
     out = torch.empty_like(scores) if out is None else out

@@ -287,6 +287,10 @@ class _PointnetSAModuleFSBase(nn.Module):
                     fused.mlp_chain3_compact(rows, cr, new_xyz, layers, pooled, col)
                     col += layers[-1][2]
                     continue
+                if gi in f['expand'] and fused.group_kernel_eligible(layers, nsample, True):
+                    fused.mlp_group3(p_all, f['pcols'][gi], layers, rows, new_xyz, pooled, col, compact=cr)
+                    col += layers[-1][2]
+                    continue
                 x = None
                 for li, (w, shift, cout, act) in enumerate(layers):
                     if li == len(layers) - 1:
@@ -305,6 +309,10 @@ class _PointnetSAModuleFSBase(nn.Module):
                 continue
             if fused.chain_eligible(rows.shape[-1], layers, nsample):   # narrow group: one fused launch
                 fused.mlp_chain3(rows, idx, new_xyz, idx_cnt, layers, pooled, col)
+                col += layers[-1][2]
+                continue
+            if gi in f['expand'] and fused.group_kernel_eligible(layers, nsample, False) and (nsample == 32 or m % 2 == 0):
+                fused.mlp_group3(p_all, f['pcols'][gi], layers, rows, new_xyz, pooled, col, idx=idx, cnt=idx_cnt)
                 col += layers[-1][2]
                 continue
             x = None

@@ -286,6 +286,21 @@ int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */
 
+/* A wide three-layer grouped MLP in ONE launch (csrc/mlp_group.hip): layer 1 from the per-point partial sums exactly as
+ * det6d_group_expand, layers 2 and 3 as fp32 MFMA GEMMs on 32-row tiles whose activations stay in LDS (weights streamed
+ * from L2 into the MFMA B fragments), then the max-pool: over the nsample rows of a centre with the empty-ball mask
+ * (dense rows: idx (B,m,ns), cnt (B*m), ns in {16, 32}) or by class over a compact row list (hdr / crow_p / crow_c; the
+ * slice of y must be zeroed: parts of one centre are combined by an integer atomic max).  Bit for bit the sequence
+ * det6d_group_expand -> det6d_linear -> det6d_linear(pool).  Widths (c1, c2, c3) in {(128,128,256), (128,256,256),
+ * (256,256,512), (256,512,1024)}: det6d_mlp_group3_supported says so.  Replaces the three Conv2d/BN/ReLU + mask +
+ * max_pool2d of a radius group (pointnet2_modules.py:462-472) and their two intermediates in memory. */
+int det6d_mlp_group3_supported(int c1, int c2, int c3, int ns, int compact);
+int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, const float *w1, int ldw1, const float *s1, int c1,
+                     const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3, const float *s3,
+                     int c3, const float *pts, int ldpts, const float *ctr, int ldctr, const int *idx, int n, int m,
+                     int ns, const int *cnt, const int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
+                     int col0, det6d_stream_t stream);
+
 /* First layer of a grouped MLP from per-point partial sums (csrc/expand.hip): with the chain order of gathered rows
  * (feature columns first, relative coordinates last) the feature part P[p][c] = chain_{k >= 3}(row_p[k] * W[k][c]) is one
  * plain det6d_linear over the points (weights with rows 0..2 zeroed, no shift, no activation), and
