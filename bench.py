@@ -265,16 +265,19 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
     saturated = family_saturated(replay, streams=streams)
     total_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
     issued = useful = 0.0
-    fill = []
-    for _, _, r, k, n in ev:
+    fill, per_launch = [], []
+    for e0, e1, r, k, n in ev:
+        us = e0.elapsed_time(e1) * 1e3
         if torch.is_tensor(r):          # compact list header: [0] issued rows, [7] centres, [8] information rows
             h = r.cpu().tolist()
             issued += 2.0 * h[0] * k * n
             useful += 2.0 * h[8] * k * n
             fill.append((h[7], h[8], h[0]))
+            per_launch.append([h[8], k, n, round(us, 1), round(2.0 * h[8] * k * n / us / 1e6, 1)])
         else:
             issued += 2.0 * r * k * n
             useful += 2.0 * r * k * n
+            per_launch.append([r, k, n, round(us, 1), round(2.0 * r * k * n / us / 1e6, 1)])
     dense = flops_per_scene * batch
     achieved = useful / (total_ms * 1e-3) / 1e12
     traffic = None
@@ -295,6 +298,8 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
             "issued_tflops": round(issued / (total_ms * 1e-3) / 1e12, 2),
             "dense_equivalent_tflops": round(dense / (total_ms * 1e-3) / 1e12, 2),
             "compact_rows_centres_information_issued": groups,
+            # every launch of the family in issue order: [information rows, K, N (fused chains: K = 1, N = sum of Cin x Cout), us, TFLOP/s]
+            "launches": per_launch,
             # the same launches with the chip FULL: one pass's GEMM-family launches captured per stream and replayed
             # concurrently on 16 streams, each starting at another launch of the pass and writing its own copies of the
             # outputs, wall clock over 24 replays each.  `achieved` above times the launches one at a time on an idle chip.
