@@ -319,7 +319,7 @@ def child_rate(args, env_extra, extra_args=(), note=""):
     env = dict(os.environ, **env_extra)
     env.pop('WORLD_SIZE', None)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
-           '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
+           '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--worker', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
            '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch),
            '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + list(extra_args)
     try:
@@ -380,6 +380,40 @@ def selfcheck(model, pipe, b):
     return bad, total
 
 
+def orchestrate(args):
+    """N = 1 with the extra legs: this process never touches the GPU.  It starts the measuring worker (headline, roofline,
+    CPU baseline), then every leg as a process of its own, ONE AT A TIME, and prints the merged line.  Measured reason: a
+    process that merely keeps its 22 idle HIP streams (hardware queues) alive slows a second process on the same GPU by
+    25 % (11 255 -> 8 445 scenes/s, scripts/r02/gpu_legtest.sh), so a leg must not run beside its parent's pipeline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ['--worker']
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    if out.returncode != 0 or not lines:
+        sys.stdout.write(out.stdout)
+        return out.returncode or 1
+    line = json.loads(lines[-1])
+    if os.environ.get('DET6D_DENSE_ROWS') is None:
+        line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
+                                        note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
+                                             "the bound for clouds whose every ball is full")
+        # the other BASELINE.json configurations (per-GPU share) and ray-cast 64-ring LiDAR scenes, same engine, same
+        # steps / warmup / timing; parity of each: tests/test_timed_path_gpu.py, tests/test_model_gpu.py
+        legs = [
+            ("configs[2] SlopedKITTI Car, batch 8 (sloped scenes, ground-aware pitch branch)",
+             ['--cfg', 'slopedkitti_models/det6d_car.yaml', '--tilt']),
+            ("configs[3] KITTI 3-class, batch 32 over 8 GPUs = 4 scenes per GPU per step",
+             ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4']),
+            ("configs[4] 65536 points per scene, batch 64 over 8 GPUs = 8 scenes per GPU per step",
+             ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8']),
+            ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
+            ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
+        ]
+        line["other_configs"] = {name: child_rate(args, {}, extra) for name, extra in legs}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def spawn_ranks(n):
     """--gpus N without torchrun: start the N rank processes (fresh interpreters, nothing in this one has touched the
     GPU) and return the worst exit code.  Mirrors what core/tools/test.py:137-143 gets from its launcher."""
@@ -430,12 +464,15 @@ def main():
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-legs', action='store_true', help='skip the child-process legs (dense rows, other BASELINE configs)')
+    ap.add_argument('--worker', action='store_true', help='(internal) the measuring process started by the orchestrating parent')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
     ap.add_argument('--h2d', action='store_true', help='PCIe-inclusive variant: every step uploads its batch from pinned host memory (never the headline value)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))       # nothing above has initialised HIP
+    if 'WORLD_SIZE' not in os.environ and not args.worker and not args.no_legs:
+        raise SystemExit(orchestrate(args))            # legs run in processes of their own, one at a time (see orchestrate)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -640,24 +677,6 @@ def main():
             line["pipeline"] = pipeline_rate(cfg, model, b, n)
         elif world == 1:
             line["compact_fill"] = compact_fill(model, points, b)
-        if world == 1 and not args.no_legs and os.environ.get('DET6D_DENSE_ROWS') is None:
-            line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
-                                            note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
-                                                 "the bound for clouds whose every ball is full")
-        if world == 1 and not args.no_legs and os.environ.get('DET6D_DENSE_ROWS') is None:
-            # the other BASELINE.json configurations (per-GPU share) and ray-cast 64-ring LiDAR scenes, same engine, same
-            # steps / warmup / timing; parity of each: tests/test_timed_path_gpu.py, tests/test_model_gpu.py
-            legs = [
-                ("configs[2] SlopedKITTI Car, batch 8 (sloped scenes, ground-aware pitch branch)",
-                 ['--cfg', 'slopedkitti_models/det6d_car.yaml', '--tilt']),
-                ("configs[3] KITTI 3-class, batch 32 over 8 GPUs = 4 scenes per GPU per step",
-                 ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4']),
-                ("configs[4] 65536 points per scene, batch 64 over 8 GPUs = 8 scenes per GPU per step",
-                 ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8']),
-                ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
-                ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
-            ]
-            line["other_configs"] = {name: child_rate(args, {}, extra) for name, extra in legs}
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)
