@@ -212,3 +212,36 @@ def test_two_rank_hip_engine_scene_sharding(tmp_path, oracle_ops):
         ref = omodel.forward(cfg.MODEL, sd, pts, 1)['pred_dicts'][0]
         np.testing.assert_array_equal(z['boxes_%d' % s], ref['pred_boxes'])
         np.testing.assert_array_equal(z['scores_%d' % s], ref['pred_scores'])
+
+
+def test_ray_cast_lidar_scenes_vs_oracle(oracle_ops):
+    """bench.py's `--scene beam` legs: 64-ring ray-cast scenes (dense near the sensor: balls 0.3-0.9 full, many exact
+    nsample-capped neighbourhoods) through the compact-row engine against the oracle's dense rows"""
+    from de6d_amd.runtime import load_config, build_model
+    from tests.util import beam_batch
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=1234, device='cuda')
+    b, n = 2, 16384
+    pts_np = flat_points(beam_batch(4100, b, n))
+    bd = {'batch_size': b, 'points': torch.from_numpy(pts_np).cuda()}
+    with torch.no_grad():
+        pred, _ = model(bd)
+    check(bd, pred, oracle_of(cfg, model, pts_np, b), b)
+
+
+def test_bench_entry_point_checks_itself():
+    """the worker of bench.py on a short run: one JSON line with the contract's keys, the steady-state timing description,
+    `selfcheck: ok` (every pass compared with the eager model inside the bench), cold / latency keys"""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '8', '--warmup', '2', '--worker',
+                          '--no-legs', '--no-roofline', '--cpu-scenes', '0', '--windows', '3', '--preroll', '1'],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'selfcheck', 'cold', 'latency', 'ranks_seen'):
+        assert key in d, key
+    assert d['selfcheck'] == 'ok' and d['steps'] == 8 and d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['value'] > 0
+    assert 'steady-state' in d['config']['timing'] and d['config']['points_per_scene'] == 16384
