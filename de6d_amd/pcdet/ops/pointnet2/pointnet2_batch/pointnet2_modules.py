@@ -202,6 +202,8 @@ class _PointnetSAModuleFSBase(nn.Module):
                 if ctl is not None and ctl.hoisted(layer, j):
                     continue          # launched by the group for all its passes, ahead of this segment (runtime.hoist_plan)
                 self._sample_one(xyz, scores, lo, hi, method, npoint, idx, off)
+            if ctl is not None:
+                ctl.after_samplers(layer, xyz, idx)    # single-graph passes: fork / join of the input-only sampler chain
             return idx
         main = torch.cuda.current_stream()
         if self._side_streams is None or len(self._side_streams) < len(jobs) - 1:

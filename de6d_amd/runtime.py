@@ -173,6 +173,77 @@ class _SegmentCapture(object):
     def hoisted(self, layer, j):
         return (layer, j) in self.front['hoisted']
 
+    def after_samplers(self, layer, xyz, idx):
+        pass                             # the group has launched them ahead of the segments
+
+
+class _InlineHoist(object):
+    """controller of a SINGLE-graph pass (GraphedDet6D without a group): the first layer's sampler runs in place, then the
+    rest of the input-only chain (hoist_plan: the d-fps halves of the later layers) is forked onto a side stream — a
+    parallel branch of the captured graph — and joined where a later layer needs its picks, so those samplers overlap
+    the first layer's MLPs and the score-weighted samplers instead of queueing behind them (latency only)."""
+
+    def __init__(self, model, batch_size, n_points):
+        from .ops import fused
+        sa = list(model.backbone_3d.SA_modules)
+        try:
+            self.plan = hoist_plan(sa, n_points)
+        except NotImplementedError:
+            self.plan = []
+        self.pack_out = None
+        self._fused = fused
+        self.side = torch.cuda.Stream()
+        self.idx, self.ctr, self.ws, self.events = {}, {}, {}, {}
+        dev = 'cuda'
+        for step in self.plan[1:]:
+            layer = step['layer']
+            if layer not in self.idx:
+                self.idx[layer] = torch.empty((batch_size, sum(sa[layer].npoint_list)), dtype=torch.int32, device=dev)
+                self.events[layer] = torch.cuda.Event()
+            self.ws[(layer, step['j'])] = fused.fps_workspace(batch_size, step['hi'] - step['lo'], dev)
+        for step in self.plan:
+            if step['feeds']:
+                self.ctr[(step['layer'], step['j'])] = torch.empty((batch_size, step['m'], 3), dtype=torch.float32, device=dev)
+        self._later = {(s['layer'], s['j']) for s in self.plan[1:]}
+        self._layer = -1
+
+    def reset(self):
+        self._layer = -1
+
+    def next_layer(self):
+        self._layer += 1
+        return self._layer
+
+    def index_buffer(self, layer, b, m):
+        return self.idx.get(layer)
+
+    def hoisted(self, layer, j):
+        return (layer, j) in self._later
+
+    def after_samplers(self, layer, xyz, idx):
+        F = self._fused
+        main = torch.cuda.current_stream()
+        if layer == 0 and self._later:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                first = self.plan[0]
+                prev_xyz, prev_idx = xyz, idx
+                for step in self.plan:
+                    key = (step['layer'], step['j'])
+                    if step is not first:
+                        src = self.ctr[step['src']]
+                        F.fps_fused(src, step['lo'], step['hi'], step['m'], None, 1.0, self.idx[step['layer']], step['offset'],
+                                    temp=self.ws[key], idx_bias=step['bias'])
+                        self.events[step['layer']].record(self.side)
+                        prev_xyz, prev_idx = src, self.idx[step['layer']]
+                    if step['feeds']:
+                        F.gather_centres(prev_xyz, prev_idx[:, step['offset']:step['offset'] + step['m']], out=self.ctr[key],
+                                         idx_bias=-step['bias'])
+        elif layer in self.events:
+            main.wait_event(self.events[layer])
+            if layer == max(self.events):
+                main.wait_stream(self.side)          # every forked branch joins the capturing stream
+
 
 class GraphedDet6D(object):
     """One Det6D pass (backbone -> head -> fused post-processing) captured into a hipGraph on its
@@ -196,7 +267,13 @@ class GraphedDet6D(object):
         if nms.MULTI_CLASSES_NMS or nms.NMS_TYPE != 'nms_gpu':
             raise NotImplementedError('graph capture needs the fused class-agnostic nms_gpu post-processing')
 
+        inline = None
+        if front is None and os.environ.get('DET6D_NO_HOIST') is None:
+            inline = _InlineHoist(model, batch_size, n_points)
+
         def body():
+            if inline is not None:
+                inline.reset()
             bd = {'batch_size': batch_size, 'points': self.points}
             for module in model.module_list:
                 bd = module(bd)
@@ -207,10 +284,14 @@ class GraphedDet6D(object):
             return bd, (boxes, scores, labels.long(), index, count)
 
         self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.no_grad(), torch.cuda.stream(self.stream):
-            for _ in range(warmup):
-                body()
-        self.stream.synchronize()
+        fused.SAMPLER_SEGMENTS = inline
+        try:
+            with torch.no_grad(), torch.cuda.stream(self.stream):
+                for _ in range(warmup):
+                    body()
+        finally:
+            fused.SAMPLER_SEGMENTS = None
+        torch.cuda.synchronize()
         self.segments = None
         if front is not None:
             torch.cuda.synchronize()
@@ -226,8 +307,12 @@ class GraphedDet6D(object):
             self.segments = ctl.segments
         else:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
-                self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
+            fused.SAMPLER_SEGMENTS = inline
+            try:
+                with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
+                    self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
+            finally:
+                fused.SAMPLER_SEGMENTS = None
         self.count_host = torch.empty(self.count.shape, dtype=self.count.dtype, pin_memory=True)
         self.done = torch.cuda.Event()
         self._weights_version = getattr(model, 'weights_version', 0)
