@@ -38,6 +38,12 @@ class LinearArgs(ctypes.Structure):
 
 
 _P = c_void_p
+class RowsLayer(ctypes.Structure):
+    """det6d_rows_layer (include/det6d_ops.h)"""
+    _fields_ = [("w", c_void_p), ("ldw", c_int), ("wrow0", c_int), ("shift", c_void_p), ("k", c_int), ("n", c_int), ("act", c_int),
+                ("out", c_void_p), ("ldo", c_int), ("ocol0", c_int)]
+
+
 class EvalMatchArgs(ctypes.Structure):
     """det6d_eval_match_args (include/det6d_ops.h)"""
     _fields_ = [("n_frames", ctypes.c_int), ("n_thresh", ctypes.c_int), ("metric", ctypes.c_int),
@@ -88,6 +94,7 @@ _SIGNATURES = {
     "det6d_mlp_group3_supported": [c_int, c_int, c_int, c_int, c_int],
     "det6d_mlp_group3": [c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
                          _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "det6d_mlp_rows": [c_int, _P, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(RowsLayer), _P],
     "det6d_group_expand": [c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
                            _P, _P, _P, _P, c_int, _P],
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],

@@ -1,0 +1,145 @@
+// mlp_rows.hip — short stacks of PLAIN pointwise layers over few rows in ONE launch: the aggregation + confidence
+// chain of an SA layer (pointnet2_modules.py:580-607: Conv1d/BN/ReLU x 1 -> Conv1d/BN/ReLU -> Conv1d), the vote FC of the
+// head (point_head_box6d_vote.py:33-45,815-818) and its cls / reg towers (:157-169, two chains over the same input).
+// As separate det6d_linear launches these are 12 of the 24 GEMM-family launches of a pass and each is latency-bound
+// (2 048 .. 32 768 rows, 0.0-0.5 GFLOP, 6-21 us on an idle chip); here a 32-row tile goes through the whole stack with
+// its activations in LDS (row-major, odd stride: conflict-free MFMA A fragments) and the weights read straight from L2
+// into the B fragments, one 16-k-step block ahead — the scheme of mlp_group.hip at run-time widths.
+// Every output is the same ascending-k fma chain as det6d_linear (+ shift, activation): bit-identical.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxLayers = 4;
+
+struct RowsArgs {
+  int rows;
+  const float *x; int ldx; int xcol0; int k0;     // input: columns [xcol0, xcol0 + k0) of x (rows, ldx)
+  int width;                                      // LDS row width (max of k0 and the hidden widths)
+  int nlayers[2];
+  det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
+};
+
+__global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
+  extern __shared__ float lds[];
+  const int LD = g.width + 1;
+  float *XA = lds, *XB = lds + 32 * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int chain = blockIdx.y;
+  const int nl = g.nlayers[chain];
+  const int ntiles_rows = (g.rows + 31) >> 5;
+  const int lrow = tid >> 3, lq = tid & 7;
+  for (int tile = blockIdx.x; tile < ntiles_rows; tile += gridDim.x) {
+    // ---- input tile -> XA (rows past the end: zeros) ----
+    {
+      const int r = tile * 32 + lrow;
+      const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0;
+      float *dst = XA + lrow * LD;
+      for (int c = lq; c < g.k0; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
+    }
+    __syncthreads();
+    for (int l = 0; l < nl; ++l) {
+      const det6d_rows_layer &L = g.layers[chain][l];
+      const float *X = (l & 1) ? XB : XA;
+      float *Y = (l & 1) ? XA : XB;
+      const bool last = l == nl - 1;
+      const __amdgpu_buffer_rsrc_t srd =
+          __builtin_amdgcn_make_buffer_rsrc((void *)(L.w + (size_t)L.wrow0 * L.ldw), 0, (unsigned)((size_t)L.k * L.ldw * 4), 0x00020000);
+      const int ldw_bytes = L.ldw * 4;
+      const int ncol_tiles = (L.n + 31) >> 5;
+      const int nblk = L.k >> 5;                      // blocks of 16 k-steps (k is a multiple of 32)
+      for (int j = wave; j < ncol_tiles; j += 4) {
+        const int col = 32 * j + l31;
+        const uint32_t voff = (uint32_t)(kh * L.ldw + col) * 4u;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        float b0[16], b1[16];
+        auto fetch = [&](float (&b)[16], int blk) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, 2 * (blk * 16 + u) * ldw_bytes, 0));
+        };
+        auto compute = [&](const float (&b)[16], int blk) {
+          const float *xa = X + l31 * LD + 32 * blk + kh;
+          float a[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a[u] = xa[2 * u];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        };
+        fetch(b0, 0);
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; blk += 2) {
+          if (blk + 1 < nblk) fetch(b1, blk + 1);
+          compute(b0, blk);
+          if (blk + 2 < nblk) fetch(b0, blk + 2);
+          if (blk + 1 < nblk) compute(b1, blk + 1);
+        }
+        const bool cok = col < L.n;
+        const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+          float v = acc[e] + sh;
+          if (L.act == 1) v = d6_relu(v);
+          if (!last && cok) Y[row * LD + col] = v;
+          const int r = tile * 32 + row;
+          if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace
+
+DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
+                             const det6d_rows_layer *layers, det6d_stream_t stream) {
+  if (rows < 0 || !x || ldx <= 0 || xcol0 < 0 || nchains < 1 || nchains > 2 || !nlayers || !layers) return DET6D_EINVAL;
+  RowsArgs g;
+  g.rows = rows; g.x = x; g.ldx = ldx; g.xcol0 = xcol0;
+  int width = 0, k0 = -1, off = 0;
+  for (int c = 0; c < 2; ++c) g.nlayers[c] = 0;
+  for (int c = 0; c < nchains; ++c) {
+    const int nl = nlayers[c];
+    if (nl < 1 || nl > kMaxLayers) return DET6D_EINVAL;
+    g.nlayers[c] = nl;
+    int kin = -1;
+    for (int l = 0; l < nl; ++l) {
+      const det6d_rows_layer &L = layers[off + l];
+      if (!L.w || L.k <= 0 || (L.k & 31) || L.n <= 0 || L.ldw < L.n || L.wrow0 < 0) return DET6D_EINVAL;
+      if (l == 0) {
+        if (k0 >= 0 && L.k != k0) return DET6D_EINVAL;      // both chains read the same input tile
+        k0 = L.k;
+      } else if (L.k != kin) {
+        return DET6D_EINVAL;                                // a hidden layer's width is the next layer's chain length
+      }
+      if (l < nl - 1 && (L.n & 31)) return DET6D_EINVAL;
+      if (l == nl - 1 && !L.out) return DET6D_EINVAL;
+      if (L.out && (L.ldo < L.ocol0 + L.n)) return DET6D_EINVAL;
+      if ((size_t)L.k * L.ldw * 4 >= 0xfff00000ull) return DET6D_EINVAL;
+      if (L.k > width) width = L.k;
+      kin = L.n;
+      g.layers[c][l] = L;
+    }
+    off += nl;
+  }
+  if (xcol0 + k0 > ldx) return DET6D_EINVAL;
+  g.k0 = k0; g.width = width;
+  if (rows == 0) return DET6D_OK;
+  const size_t lds_bytes = sizeof(float) * 2 * 32 * (size_t)(width + 1);
+  if (lds_bytes > 160 * 1024) return DET6D_EINVAL;
+  static size_t attr_bytes = 0;
+  if (lds_bytes > attr_bytes) {
+    hipFuncSetAttribute((const void *)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_bytes = lds_bytes;
+  }
+  int blocks = (rows + 31) / 32;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mlp_rows_kernel, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+  return det6d_check_launch("det6d_mlp_rows");
+}

@@ -254,6 +254,56 @@ def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, c
     return out
 
 
+#: short stacks of plain layers in one launch (csrc/mlp_rows.hip); DET6D_NO_ROWS_KERNEL=1: one det6d_linear per layer
+ROWS_KERNEL = os.environ.get('DET6D_NO_ROWS_KERNEL') is None
+
+
+def mlp_rows_eligible(k0, chains):
+    """chains: [[(w, wrow0, shift, k, n, act, out, ocol0), ...], ...]"""
+    if not ROWS_KERNEL or not 1 <= len(chains) <= 2 or k0 % 32 or k0 > 1024:
+        return False
+    for chain in chains:
+        if not 1 <= len(chain) <= 4 or chain[0][3] != k0:
+            return False
+        kin = k0
+        for li, (w, wrow0, shift, k, n, act, out, ocol0) in enumerate(chain):
+            last = li == len(chain) - 1
+            if k != kin or k % 32 or k > 1024 or (not last and n % 32) or (last and out is None) or act not in (0, 1):
+                return False
+            kin = n
+    return True
+
+
+def mlp_rows(x, xcol0, chains):
+    """x (R, ldx) device rows; every chain reads columns [xcol0, xcol0 + k0) of it; see mlp_rows_eligible for the spec"""
+    L.require_cuda(x)
+    rows = x.numel() // x.shape[-1]
+    flat = [l for chain in chains for l in chain]
+    counts = (ctypes.c_int * len(chains))(*[len(c) for c in chains])
+
+    def issue(ptr_of=None):
+        arr = (L.RowsLayer * len(flat))()
+        for d, (w, wrow0, shift, k, n, act, out, ocol0) in zip(arr, flat):
+            d.w, d.ldw, d.wrow0 = w.data_ptr(), w.shape[1], wrow0
+            d.shift = shift.data_ptr() if shift is not None else None
+            d.k, d.n, d.act = k, n, act
+            if out is not None:
+                d.out, d.ldo, d.ocol0 = (out.data_ptr() if ptr_of is None else ptr_of(out)), out.shape[-1], ocol0
+        L.call("det6d_mlp_rows", rows, L.ptr(x) if ptr_of is None else ctypes.c_void_p(ptr_of(x)), x.shape[-1], xcol0, len(chains),
+               counts, arr, L.stream_ptr())
+    ev = None
+    if LINEAR_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if LINEAR_REPLAY is not None:
+        outs = [l[6] for l in flat if l[6] is not None]
+        LINEAR_REPLAY.append((issue, outs[-1], (x, chains)))
+    issue()
+    if ev is not None:
+        ev[1].record()
+        LINEAR_EVENTS.append((ev[0], ev[1], rows, 1, sum(l[3] * l[4] for l in flat)))
+
+
 def sigmoid_pow(scores, gamma, out=None):
     L.require_cuda(scores)
     out = torch.empty_like(scores) if out is None else out

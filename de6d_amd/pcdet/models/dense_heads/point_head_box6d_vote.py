@@ -110,7 +110,16 @@ class PointHeadBox6DVote(nn.Module):
         p = cand_rows.shape[1]
 
         # vote offsets -> clamp -> vote points (point_head_box6d_vote.py:815-821)
-        off = run_chain(cand_rows, f['vote'])                       # (B*P, 4), cols 0..2 valid
+        vote = f['vote']
+        spec, kin, wrow0 = [], self.input_channels, 3               # the chain starts at weight row 3 (rows 0..2: coordinates, zero)
+        off = torch.empty((b * p, round4(vote[-1][2])), dtype=torch.float32, device=rows.device)
+        for li, (w, sh, cout, act) in enumerate(vote):
+            spec.append((w, wrow0, sh, kin, cout, act, off if li == len(vote) - 1 else None, 0))
+            kin, wrow0 = cout, 0
+        if fused.mlp_rows_eligible(self.input_channels, [spec]):    # vote FC stack in one launch (csrc/mlp_rows.hip)
+            fused.mlp_rows(cand_rows.view(b * p, ld), 3, [spec])
+        else:
+            off = run_chain(cand_rows, f['vote'])                   # (B*P, 4), cols 0..2 valid
         vote_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=rows.device)
         off_clamped = torch.empty((b * p, 3), dtype=torch.float32, device=rows.device)
         fused.vote_points(off, cand_rows, self.vote_cfg.MAX_TRANSLATION_RANGE, vote_xyz, off_clamped)
@@ -120,9 +129,22 @@ class PointHeadBox6DVote(nn.Module):
         shared = run_chain(pooled.view(b * p, -1), f['shared'])
         ncls, ncode = f['cls'][-1][2], f['reg'][-1][2]
         point_cls_preds = torch.empty((b * p, ncls), dtype=torch.float32, device=rows.device)
-        run_chain(shared, f['cls'], out=point_cls_preds)            # the last layer writes the unpadded (B*P, ncls) logits
-        reg = run_chain(shared, f['reg'])
-        point_reg_preds = reg[:, :ncode].contiguous() if reg.shape[1] != ncode else reg
+        kshared = f['shared'][-1][2]
+
+        def tower(layers, out):
+            spec, kin = [], kshared
+            for li, (w, sh, cout, act) in enumerate(layers):
+                spec.append((w, 0, sh, kin, cout, act, out if li == len(layers) - 1 else None, 0))
+                kin = cout
+            return spec
+        point_reg_preds = torch.empty((b * p, ncode), dtype=torch.float32, device=rows.device)
+        towers = [tower(f['cls'], point_cls_preds), tower(f['reg'], point_reg_preds)]
+        if shared.shape[1] == kshared and fused.mlp_rows_eligible(kshared, towers):
+            fused.mlp_rows(shared, 0, towers)                       # cls and reg towers: two chains, one launch (csrc/mlp_rows.hip)
+        else:
+            run_chain(shared, f['cls'], out=point_cls_preds)        # the last layer writes the unpadded (B*P, ncls) logits
+            reg = run_chain(shared, f['reg'])
+            point_reg_preds = reg[:, :ncode].contiguous() if reg.shape[1] != ncode else reg
 
         vote_flat = vote_xyz.view(b * p, 3)
         boxes = self.box_coder.decode_torch(point_reg_preds, vote_flat)

@@ -341,6 +341,21 @@ class _PointnetSAModuleFSBase(nn.Module):
             if new_rows is None:  # centres supplied by the caller
                 new_rows = torch.zeros((b, m, rows_ld(f['out_channels'])), dtype=torch.float32, device=rows.device)
                 new_rows[:, :, :3] = new_xyz
+            if f['conf'] is not None and f['conf'][-1][2] == 1 and len(f['agg']) == 1:
+                # aggregation + confidence chain in ONE launch (csrc/mlp_rows.hip): the aggregated features go to the next
+                # level's rows AND stay in LDS as the input of the confidence layers (whose first three weight rows, the
+                # coordinates', are zero: the chain starts at weight row 3)
+                wa, sha, ca, aa = f['agg'][0]
+                new_scores = torch.empty((b * m, 1), dtype=torch.float32, device=rows.device)
+                spec = [(wa, 0, sha, f['pooled_width'], ca, aa, new_rows.view(b * m, -1), 3)]
+                kin, wrow0 = ca, 3
+                for li, (w, sh, cout, act) in enumerate(f['conf']):
+                    spec.append((w, wrow0, sh, kin, cout, act, new_scores if li == len(f['conf']) - 1 else None, 0))
+                    kin, wrow0 = cout, 0
+                if fused.mlp_rows_eligible(f['pooled_width'], [spec]):
+                    fused.mlp_rows(pooled, 0, [spec])
+                    return new_xyz, new_rows, new_scores.view(b, m)
+                new_scores = None
             run_chain(pooled, f['agg'], out=new_rows, col0=3)
             if f['conf'] is not None and f['conf'][-1][2] == 1:   # the last layer writes the (B*M, 1) score column itself
                 new_scores = torch.empty((b * m, 1), dtype=torch.float32, device=rows.device)

@@ -286,6 +286,22 @@ int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */
 
+/* Short stacks of plain pointwise layers over few rows in ONE launch (csrc/mlp_rows.hip): the aggregation + confidence
+ * chain of an SA layer (pointnet2_modules.py:580-607), the vote FC and the cls / reg towers of the head
+ * (point_head_box6d_vote.py:33-45,157-169).  Input: columns [xcol0, xcol0 + k) of x (rows, ldx), k = layers[0].k.
+ * Layer l: y = act(in[0..k) x W[wrow0 .. wrow0 + k)[0..n) + shift); k % 32 == 0; hidden widths n % 32 == 0 and equal to the
+ * next layer's k; `out` (rows, ldo) optional for hidden layers, required for the last; 1 or 2 chains over the same input
+ * (nlayers[c] layers each, stored back to back in `layers`), at most 4 layers per chain.  Bit for bit the corresponding
+ * sequence of det6d_linear calls. */
+typedef struct det6d_rows_layer {
+  const float *w; int ldw; int wrow0;
+  const float *shift;
+  int k, n, act;
+  float *out; int ldo; int ocol0;
+} det6d_rows_layer;
+int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
+                   const det6d_rows_layer *layers, det6d_stream_t stream);
+
 /* A wide three-layer grouped MLP in ONE launch (csrc/mlp_group.hip): layer 1 from the per-point partial sums exactly as
  * det6d_group_expand, layers 2 and 3 as fp32 MFMA GEMMs on 32-row tiles whose activations stay in LDS (weights streamed
  * from L2 into the MFMA B fragments), then the max-pool: over the nsample rows of a centre with the empty-ball mask
