@@ -8,7 +8,7 @@ for roofline.traffic (HBM bytes per GEMM-family launch).
 """
 import csv, glob, json, sys, collections
 root, steps = sys.argv[1], int(sys.argv[2])
-FAMILIES = ('linear_kernel', 'mlp_chain', 'mlp_group', 'group_expand', 'compact_groups', 'fps_coop', 'fps_skip_kernel', 'fps_fat_kernel', 'ball_query_pair_kernel', 'bq_grid', 'post_',
+FAMILIES = ('linear_kernel', 'mlp_chain', 'mlp_group', 'mlp_rows', 'group_expand', 'compact_groups', 'fps_coop', 'fps_skip_kernel', 'fps_fat_kernel', 'ball_query_pair_kernel', 'bq_grid', 'post_',
             'gather_rows', 'pack_points')
 out = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
@@ -25,14 +25,14 @@ res = {}
 for fam, ctrs in out.items():
     res[fam] = {c: v / steps for c, v in ctrs.items()}
     res[fam]['dispatches_per_step'] = max(len(ndisp[(fam, c)]) for c in ctrs) / steps
-gemm = [res[f] for f in ('linear_kernel', 'mlp_chain', 'mlp_group') if f in res]
+gemm = [res[f] for f in ('linear_kernel', 'mlp_chain', 'mlp_group', 'mlp_rows') if f in res]
 if gemm and all('FETCH_SIZE' in g and 'WRITE_SIZE' in g for g in gemm):
     rd = sum(g['FETCH_SIZE'] for g in gemm) * 1024.0 * 2.0
     wr = sum(g['WRITE_SIZE'] for g in gemm) * 1024.0
     launches = sum(g['dispatches_per_step'] for g in gemm)
     d = {'launches_per_step': launches, 'hbm_read_bytes_per_step_corrected_x2': rd, 'hbm_write_bytes_per_step': wr,
          'hbm_bytes_per_launch': (rd + wr) / launches,
-         'note': 'GEMM family = linear_kernel + mlp_chain_{reg,wide,}_kernel + mlp_group_kernel; rocprofv3 --pmc, separate passes for FETCH_SIZE / '
+         'note': 'GEMM family = linear_kernel + mlp_chain_{reg,wide,}_kernel + mlp_group_kernel + mlp_rows_kernel; rocprofv3 --pmc, separate passes for FETCH_SIZE / '
                  'WRITE_SIZE / SQ counters; bench.py --streams 1 --no-graph; FETCH_SIZE doubled per '
                  'MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request for 16 B/lane reads)'}
     busy = sum(g.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for g in gemm)
