@@ -98,7 +98,28 @@ def index_kernel_rates(model, points, batch, n):
     e[2].record(); F.ball_query_pair(xyz, ctr, shells[0], shells[1]); e[3].record()
     torch.cuda.synchronize()
     t_fps, t_bq = e[0].elapsed_time(e[1]) * 1e-3, e[2].elapsed_time(e[3]) * 1e-3
+    # every sampler of the backbone stand-alone (us per round = per dependent pick): layer, method, points -> picks
+    per_round = {}
+    cloud = xyz
+    for li, sa_l in enumerate(model.backbone_3d.SA_modules):
+        n_l = cloud.shape[1]
+        idx_l = torch.empty((batch, sum(sa_l.npoint_list)), dtype=torch.int32, device='cuda')
+        sc_l = torch.randn((batch, n_l), device='cuda')
+        off = 0
+        for (lo, hi), method, npoint in zip(sa_l.sample_range_list, sa_l.sample_method_list, sa_l.npoint_list):
+            hi = n_l if hi == -1 else hi
+            ws_l = F.fps_workspace(batch, hi - lo)
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(2):
+                s0.record()
+                F.fps_fused(cloud, lo, hi, npoint, sc_l if method == 's-fps' else None, 1.0, idx_l, off, temp=ws_l)
+                s1.record()
+            torch.cuda.synchronize()
+            per_round["SA%d %s %d->%d" % (li + 1, method, hi - lo, npoint)] = round(s0.elapsed_time(s1) * 1e3 / max(npoint - 1, 1), 3)
+            off += npoint
+        cloud = F.gather_centres(cloud, idx_l)
     out = {"fps_sa1_ms": round(t_fps * 1e3, 3), "fps_pair_evals_per_s": round(batch * (m - 1) * n / t_fps, 0),
+           "fps_us_per_round": per_round,
            "ball_query_sa1_ms": round(t_bq * 1e3, 3),
            "bq_pair_evals_per_s_upper_bound_work": round(2.0 * batch * m * n / t_bq, 0)}
     # SURVEY.md 8a rows a15 / a13, stand-alone (not on Det6D's FSMSG path): three_nn + three_interpolate of (B, 64, m)
