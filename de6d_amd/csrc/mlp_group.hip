@@ -143,10 +143,11 @@ __device__ __forceinline__ void group_layer(const float *__restrict__ X, const _
   }
 }
 
-template <int C1, int C2, int C3, bool COMPACT>
-__global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
+template <int C1, int C2, int C3, bool COMPACT, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
   constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
-  constexpr int TN2 = C2 / 128, TN3 = C3 / 128;
+  constexpr int TN2 = C2 / (32 * NW), TN3 = C3 / (32 * NW);     // accumulator tiles per wave: a wave owns 1 / NW of every layer's columns
+  static_assert(TN2 >= 1 && TN3 >= 1, "every wave needs at least one 32-column tile per layer");
   extern __shared__ float lds[];
   float *X1 = lds;
   float *X2 = lds + 32 * LD1;
@@ -158,16 +159,17 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
 
   const __amdgpu_buffer_rsrc_t srd2 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w2, 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w3, 0, 0xffffffff, 0x00020000);
-  const uint32_t voff2 = (uint32_t)(kh * g.ldw2 + wave * (C2 / 4) + tile_col<TN2>(0, l31)) * 4u;
-  const uint32_t voff3 = (uint32_t)(kh * g.ldw3 + wave * (C3 / 4) + tile_col<TN3>(0, l31)) * 4u;
+  const uint32_t voff2 = (uint32_t)(kh * g.ldw2 + wave * (C2 / NW) + tile_col<TN2>(0, l31)) * 4u;
+  const uint32_t voff3 = (uint32_t)(kh * g.ldw3 + wave * (C3 / NW) + tile_col<TN3>(0, l31)) * 4u;
   float sh2[TN2], sh3[TN3];
 #pragma unroll
-  for (int j = 0; j < TN2; ++j) sh2[j] = g.s2[wave * (C2 / 4) + tile_col<TN2>(j, l31)];
+  for (int j = 0; j < TN2; ++j) sh2[j] = g.s2[wave * (C2 / NW) + tile_col<TN2>(j, l31)];
 #pragma unroll
-  for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / 4) + tile_col<TN3>(j, l31)];
+  for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / NW) + tile_col<TN3>(j, l31)];
 
   // layer 1 (expand): thread (row = tid / 8, q = tid % 8) produces columns 4q + 32 i of its row
-  const int erow = tid >> 3, eq = tid & 7;
+  constexpr int EPR = 2 * NW;                     // threads per row in the expand phase
+  const int erow = tid / EPR, eq = tid % EPR;
 
   for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
     // ---- layer 1: X1[row][c] = relu(fma(dz, W1[2][c], fma(dy, W1[1][c], fma(dx, W1[0][c], P[p][c]))) + s1[c]) ----
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
       const float *prow_p = g.p + (real ? prow : 0) * g.ldp + g.pcol0;
       float *xr = X1 + erow * LD1;
 #pragma unroll 4
-      for (int c = 4 * eq; c < C1; c += 32) {
+      for (int c = 4 * eq; c < C1; c += 4 * EPR) {
         const f32x4g pv = *reinterpret_cast<const f32x4g *>(prow_p + c);
         const f32x4g wx = *reinterpret_cast<const f32x4g *>(g.w1 + c);
         const f32x4g wy = *reinterpret_cast<const f32x4g *>(g.w1 + g.ldw1 + c);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
       group_layer<C1, TN2, LD1>(X1, srd2, voff2, g.ldw2 * 4, acc, l31, kh);
 #pragma unroll
       for (int j = 0; j < TN2; ++j) {
-        float *xc = X2 + wave * (C2 / 4) + tile_col<TN2>(j, l31);
+        float *xc = X2 + wave * (C2 / NW) + tile_col<TN2>(j, l31);
 #pragma unroll
         for (int e = 0; e < 16; ++e) xc[((e & 3) + 8 * (e >> 2) + 4 * kh) * LD2] = d6_relu(acc[j][e] + sh2[j]);
       }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
           if (sc == 2 && (e & 1)) continue;
           const int tag = g.crow_c[tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
           if (tag < 0) continue;
-          float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / 4);
+          float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / NW);
 #pragma unroll
           for (int j = 0; j < TN3; ++j) {
             const float raw = sc == 2 ? d6_vmax(acc[j][e], acc[j][e + 1 < 16 ? e + 1 : e]) : acc[j][e];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
             if (oc[qq] >= 0)
-              g_store(g.y + (size_t)(oc[qq] & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / 4) + tile_col<TN3>(j, l31),
+              g_store(g.y + (size_t)(oc[qq] & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / NW) + tile_col<TN3>(j, l31),
                       (oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]), oc[qq]);
         }
       }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
           const float mq = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
           q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
         }
-        float *dst = g.y + g.col0 + wave * (C3 / 4) + tile_col<TN3>(j, l31);
+        float *dst = g.y + g.col0 + wave * (C3 / NW) + tile_col<TN3>(j, l31);
         if (kh == 0) {
           if (g.ns == 32) {
             const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
@@ -296,12 +298,12 @@ __global__ __launch_bounds__(256) void mlp_group_kernel(const GroupArgs g) {
   }
 }
 
-template <int C1, int C2, int C3, bool COMPACT>
+template <int C1, int C2, int C3, bool COMPACT, int NW>
 int launch_group(const GroupArgs &g, hipStream_t stream) {
   const size_t lds_bytes = sizeof(float) * 32 * (size_t)(C1 + 1 + C2 + 1);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void *)mlp_group_kernel<C1, C2, C3, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_group_kernel<C1, C2, C3, COMPACT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_set = true;
   }
   int per_cu = (int)((160 * 1024) / lds_bytes);
@@ -309,7 +311,7 @@ int launch_group(const GroupArgs &g, hipStream_t stream) {
   if (per_cu < 1) per_cu = 1;
   int blocks = g.rows / 32;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((mlp_group_kernel<C1, C2, C3, COMPACT>), dim3(blocks), dim3(256), lds_bytes, stream, g);
+  hipLaunchKernelGGL((mlp_group_kernel<C1, C2, C3, COMPACT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, stream, g);
   return det6d_check_launch("det6d_mlp_group3");
 }
 
@@ -349,13 +351,19 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
   g.y = y; g.ldy = ldy; g.col0 = col0;
   hipStream_t s = (hipStream_t)stream;
-#define D6_GROUP(A, B, C)                                                               \
-  if (c1 == A && c2 == B && c3 == C)                                                    \
-    return compact ? launch_group<A, B, C, true>(g, s) : launch_group<A, B, C, false>(g, s)
-  D6_GROUP(128, 128, 256);
-  D6_GROUP(128, 256, 256);
-  D6_GROUP(256, 256, 512);
-  D6_GROUP(256, 512, 1024);
+  // waves per 32-row tile: 8 for the head's groups (two waves per SIMD from ONE workgroup: the 99 KB of LDS allow only one
+  // workgroup per CU), 4 for the SA3 groups (several workgroups per CU); DET6D_GROUP_WAVES (experiments build) overrides
+  static const int nw_env = det6d_env_int("DET6D_GROUP_WAVES", 0);
+#define D6_GROUP(A, B, C, NWD)                                                                        \
+  if (c1 == A && c2 == B && c3 == C) {                                                                \
+    if ((nw_env ? nw_env : NWD) == 8 && B >= 256)                                                     \
+      return compact ? launch_group<A, B, C, true, (B >= 256 ? 8 : 4)>(g, s) : launch_group<A, B, C, false, (B >= 256 ? 8 : 4)>(g, s); \
+    return compact ? launch_group<A, B, C, true, 4>(g, s) : launch_group<A, B, C, false, 4>(g, s);    \
+  }
+  D6_GROUP(128, 128, 256, 4)
+  D6_GROUP(128, 256, 256, 4)
+  D6_GROUP(256, 256, 512, 8)
+  D6_GROUP(256, 512, 1024, 8)
 #undef D6_GROUP
   return DET6D_EINVAL;
 }
