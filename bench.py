@@ -329,6 +329,10 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
             "compact_rows_centres_information_issued": groups,
             # every launch of the family in issue order: [information rows, K, N (fused chains: K = 1, N = sum of Cin x Cout), us, TFLOP/s]
             "launches": per_launch,
+            # the single longest launch of a pass (mlp_group_kernel of the head's wide radius group) on its own
+            "dominant_launch": (lambda x: {"information_rows": x[0], "flop_per_row": 2 * x[1] * x[2], "us": x[3], "tflops": x[4],
+                                           "frac": round(x[4] / MFMA_F32_PEAK_TFLOPS, 4),
+                                           "share_of_family_time": round(x[3] / (total_ms * 1e3), 3)})(max(per_launch, key=lambda x: x[3])),
             # the same launches with the chip FULL: one pass's GEMM-family launches captured per stream and replayed
             # concurrently on 16 streams, each starting at another launch of the pass and writing its own copies of the
             # outputs, wall clock over 24 replays each.  `achieved` above times the launches one at a time on an idle chip.
