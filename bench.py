@@ -4,22 +4,24 @@
 One "step" = one full pass (PointNet2FSMSG backbone -> PointHeadBox6DVote -> rotated NMS
 post-processing, detections sliced per scene) over one batch of 8 synthetic 16384-point
 KITTI-like scenes already resident in HBM (BASELINE.json configs[1]).  The passes run through a
-two-stage software pipeline (de6d_amd/runtime.py: Det6DGroup): stage 1 = pack + farthest point
-sampling of the input clouds of a GROUP of 4 passes, one launch on a sampler stream, issued 4
-groups ahead; stage 2 = the rest of every pass (captured hipGraph segments) on 16 main streams,
-so the latency-bound sampling rounds (one workgroup per scene) overlap the MFMA GEMMs of other
-passes.  Every pass still processes its own batch of 8 scenes and every step is finalised (its
-per-scene detections materialised on the host side) inside the timed region.
+two-stage software pipeline (de6d_amd/runtime.py: ScenePipeline / Det6DGroup): stage 1 = pack + the samplers
+that depend on nothing but the input cloud (D-FPS of the input, then the d-fps halves of the later layers over
+its picks) for a GROUP of 4 passes, one launch each on a sampler stream, issued 4 groups ahead; stage 2 = the
+rest of every pass (captured hipGraph segments) on 16 main streams, so the latency-bound sampling rounds (one
+workgroup per scene) overlap the MFMA GEMMs of other passes.  Every pass still processes its own batch of 8
+scenes and every step is finalised (its per-scene detections materialised on the host side) inside the timed
+region.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Timing: the pipeline holds up to 32 passes (16 in their GEMM stage + 4 prefetched sampler groups of 4), so a
 sync-bracketed run of K steps is mostly pipeline fill + drain when K is small.  `value` is therefore measured
-over a STEADY-STATE WINDOW: one continuous stream of P + W + K + T steps is issued (P = pre-roll that fills the
-pipeline, W = --warmup, T = tail that keeps it full), with barrier + synchronize before and after the stream,
-and the clock runs from the finalisation of step P+W-1 to the finalisation of step P+W+K-1: exactly K steps are
-finalised (detections of every scene materialised) inside the window.  The sync-bracketed time of K steps on an
+over STEADY-STATE WINDOWS: one continuous stream of steps is issued (a pre-roll that fills the pipeline and lets the
+clocks settle, --warmup steps, the windows, a tail that keeps the pipeline full), with barrier + synchronize before
+and after the stream; a window runs from the finalisation of step s to the finalisation of step s + K — exactly K
+steps are finalised (detections of every scene materialised) inside it — and `value` is the MEDIAN of 17 such
+windows starting on consecutive group boundaries (passes complete in bursts: a single window of K = 20 is +-17 % noisy).  The sync-bracketed time of K steps on an
 empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the timed region
 every pass's last result is compared with an eager pass over the same batch (`selfcheck`); a mismatch exits
 non-zero.
@@ -27,7 +29,9 @@ non-zero.
 N > 1: one process per GPU, scenes sharded (weak scaling, 8 scenes per GPU per step), no collective on the data
 path; RCCL is used only for the barrier and the max-over-ranks of the window time.  Without torchrun
 (`WORLD_SIZE` unset) `--gpus N` starts the N rank processes itself, before anything touches the GPU.  Rank 0
-prints ONE JSON line.
+prints ONE JSON line.  N = 1 without `--worker`: an orchestrating parent that never touches the GPU starts the
+measuring worker and then the extra legs (dense rows, the other BASELINE configurations, ray-cast LiDAR scenes) as
+processes of their own, one at a time, and prints the merged line.
 """
 import argparse
 import json

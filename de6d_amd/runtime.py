@@ -86,11 +86,11 @@ def mlp_flops_per_scene(model, n_points):
 
 #: Farthest point sampling is ONE 1024-thread workgroup per scene running a 4095-round latency chain.  Inside a
 #: stream of GEMM workgroups at equal queue priority such a workgroup waits 10-20 ms for a CU with enough free
-#: registers / wave slots (scripts/gpu_cumask.py: 3.6 ms alone, 19 ms beside four GEMM streams, 5.5 ms from a
+#: registers / wave slots (scripts/experiments/gpu_cumask.py: 3.6 ms alone, 19 ms beside four GEMM streams, 5.5 ms from a
 #: high-priority queue), which kept 22 passes in flight, most of them waiting for a sampler.  HIP gives
-#: high-priority streams only FOUR hardware queues (scripts/gpu_prio_queues.py), so instead the first sampler — the
-#: one that depends on nothing but the input cloud — is cut out of the captured passes and launched ONCE for a group
-#: of passes on a sampler stream, AHEAD of the passes' GEMM stage (Det6DGroup); everything else replays as graph
+#: high-priority streams only FOUR hardware queues (scripts/experiments/gpu_prio_queues.py), so instead the samplers
+#: that depend on nothing but the input cloud (hoist_plan) are cut out of the captured passes and launched ONCE for a
+#: group of passes on a sampler stream, AHEAD of the passes' GEMM stage (Det6DGroup); everything else replays as graph
 #: segments on the main streams.
 SAMPLER_GROUP = 4   # passes per group in bench.py (--group)
 
@@ -328,7 +328,7 @@ class GraphedDet6D(object):
                                "its graph still points at the old folded matrices; build a new GraphedDet6D / Det6DGroup")
 
     def launch_front(self, points=None):
-        """segment 0 (everything before the first sampler) on the CURRENT stream (the group's sampler stream), once
+        """segment 0 (everything before the first SA layer's samplers) on the CURRENT stream (the group's sampler stream), once
         the pass's previous launch has finished with the buffers"""
         self._check_weights()
         self._relaunched()
@@ -464,7 +464,7 @@ def warn_hw_queues(need):
 
 class ScenePipeline(object):
     """The throughput runner: batches of scenes stream through `n_main / group + prefetch` Det6DGroups.
-    Stage 1 of a group (pack + first sampler of its `group` passes) is issued `prefetch` groups ahead on one of the
+    Stage 1 of a group (pack + the input-only samplers of its `group` passes) is issued `prefetch` groups ahead on one of the
     sampler streams, stage 2 (the captured rest of every pass) on `n_main` main streams; a pass is finalised (its
     detections sliced per scene, the only host sync) when the slot it occupies is needed again.
 
