@@ -243,3 +243,117 @@ def test_model_parity_on_the_other_row_paths(env):
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout
+
+
+@pytest.mark.parametrize("c_in,widths,ns", [(128, (128, 128, 256), 16), (128, (128, 256, 256), 32), (256, (256, 256, 512), 16),
+                                            (256, (256, 512, 1024), 32)])
+@pytest.mark.parametrize("smin,split", [(1, 1), (4, 4), (1, 0), (2, 8)])
+def test_group_kernel_equals_dense_oracle(oracle_ops, c_in, widths, ns, smin, split):
+    """csrc/mlp_group.hip: per-point first-layer sums + ONE launch for layers 2, 3 and the pooling, over compact lists of
+    every granularity and over the dense rows, == the oracle's three layers over ALL nsample rows (bit for bit)"""
+    from de6d_amd.ops import fused
+    b, n, m = 2, 700, 334
+    rng = np.random.default_rng(sum(widths) + ns + smin)
+    ld = (3 + c_in + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3 + c_in] = rng.normal(size=(b, n, 3 + c_in))
+    ctr = rng.normal(size=(b, m, 3)).astype(np.float32)
+    cnt, idx = padded_query(rng, b, n, m, ns)
+    layers_np, layers_dev = make_layers(rng, ld, c_in, widths)
+    h = oracle_ops.linear(rows, layers_np[0][0], layers_np[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(h, layers_np[1][0], layers_np[1][1], 1)
+    ref = np.full((b * m, widths[2] + 4), -7.0, np.float32)
+    oracle_ops.linear(h, layers_np[2][0][:, :widths[2]], layers_np[2][1], 1, cnt=cnt, pool=ns, out=ref, col0=4)
+    d_rows, d_ctr = dev(rows), dev(ctr)
+    wz = layers_dev[0][0].clone()
+    wz[:3] = 0
+    p = torch.empty((b * n, wz.shape[1] + 8), device="cuda")            # this group's sums at column 8 of a wider P
+    fused.linear(d_rows.view(b * n, ld), wz, None, 0, p, col0=8)
+    assert fused.group_kernel_eligible(layers_dev, ns, True) and fused.group_kernel_eligible(layers_dev, ns, False)
+    # compact list
+    out = torch.full((b * m, widths[2] + 4), -7.0, device="cuda")
+    out[:, 4:] = 0.0
+    cr = build_list(fused, cnt, idx, n, smin, split)
+    fused.mlp_group3(p, 8, layers_dev, d_rows, d_ctr, out, 4, compact=cr)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # dense rows
+    out2 = torch.full((b * m, widths[2] + 4), -7.0, device="cuda")
+    fused.mlp_group3(p, 8, layers_dev, d_rows, d_ctr, out2, 4, idx=dev(idx), cnt=dev(cnt))
+    np.testing.assert_array_equal(out2.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("case", ["all_empty", "all_full", "all_single", "one_centre"])
+def test_group_kernel_on_degenerate_lists(oracle_ops, case):
+    from de6d_amd.ops import fused
+    c_in, widths, ns = 128, (128, 256, 256), 32
+    b, n, m = 2, 300, 64 if case != "one_centre" else 1
+    rng = np.random.default_rng(5)
+    ld = (3 + c_in + 3) // 4 * 4
+    rows = np.zeros((b, n, ld), np.float32)
+    rows[..., :3 + c_in] = rng.normal(size=(b, n, 3 + c_in))
+    ctr = rng.normal(size=(b, m, 3)).astype(np.float32)
+    cnt = {"all_empty": np.zeros((b, m)), "all_full": np.full((b, m), ns), "all_single": np.ones((b, m)),
+           "one_centre": np.full((b, m), 21)}[case].astype(np.int32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    for bi in range(b):
+        for j in range(m):
+            c = max(int(cnt[bi, j]), 1)
+            if cnt[bi, j] == 0:
+                idx[bi, j] = 0
+            idx[bi, j] = np.resize(idx[bi, j, :c], ns)
+    layers_np, layers_dev = make_layers(rng, ld, c_in, widths)
+    h = oracle_ops.linear(rows, layers_np[0][0], layers_np[0][1], 1, idx=idx, ctr=ctr)
+    h = oracle_ops.linear(h, layers_np[1][0], layers_np[1][1], 1)
+    ref = oracle_ops.linear(h, layers_np[2][0][:, :widths[2]], layers_np[2][1], 1, cnt=cnt, pool=ns)
+    wz = layers_dev[0][0].clone()
+    wz[:3] = 0
+    p = torch.empty((b * n, wz.shape[1]), device="cuda")
+    fused.linear(dev(rows).view(b * n, ld), wz, None, 0, p)
+    out = torch.zeros((b * m, widths[2]), device="cuda")
+    cr = build_list(fused, cnt, idx, n, 1, 1)
+    fused.mlp_group3(p, 0, layers_dev, dev(rows), dev(ctr), out, 0, compact=cr)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("rows_n", [1, 33, 2047, 4096])
+def test_plain_layer_stacks_equal_the_layer_by_layer_oracle(oracle_ops, rows_n):
+    """csrc/mlp_rows.hip: aggregation + confidence chain (a hidden layer stored AND fed on), a two-chain launch over one
+    input (cls / reg towers), ragged row counts, N = 1 / 3 / 32 outputs — == oracle linear, layer by layer"""
+    from de6d_amd.ops import fused
+    rng = np.random.default_rng(rows_n)
+
+    def layer(k_rows, k_used, k0, n_out, act):
+        w = np.zeros((k_rows, (n_out + 3) // 4 * 4), np.float32)
+        w[k0:k0 + k_used, :n_out] = rng.normal(size=(k_used, n_out)) / np.sqrt(k_used)
+        return w, rng.normal(size=(n_out,)).astype(np.float32), n_out, act
+    # aggregation 96 -> 64 (stored at column 3 of 68-wide rows), confidence 64 -> 32 -> 1 reading weight rows 3..66
+    x = rng.normal(size=(rows_n, 96)).astype(np.float32)
+    agg, c1, c2 = layer(96, 96, 0, 64, 1), layer(68, 64, 3, 32, 1), layer(32, 32, 0, 1, 0)
+    new_rows = torch.full((rows_n, 68), 9.0, device="cuda")
+    scores = torch.empty((rows_n, 1), device="cuda")
+    spec = [(dev(agg[0]), 0, dev(agg[1]), 96, 64, 1, new_rows, 3), (dev(c1[0]), 3, dev(c1[1]), 64, 32, 1, None, 0),
+            (dev(c2[0]), 0, dev(c2[1]), 32, 1, 0, scores, 0)]
+    assert fused.mlp_rows_eligible(96, [spec])
+    fused.mlp_rows(dev(x), 0, [spec])
+    a = oracle_ops.linear(x, agg[0][:, :64], agg[1], 1)
+    feat_rows = np.zeros((rows_n, 68), np.float32)
+    feat_rows[:, 3:67] = a
+    h = oracle_ops.linear(feat_rows, c1[0][:, :32], c1[1], 1)
+    sc = oracle_ops.linear(h, c2[0][:, :1], c2[1], 0)
+    got = new_rows.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 3:67], a)
+    assert (got[:, :3] == 9.0).all() and (got[:, 67] == 9.0).all()
+    np.testing.assert_array_equal(scores.cpu().numpy(), sc)
+    # two towers over one 512-wide input: 512 -> 128 -> 3 and 512 -> 128 -> 32
+    x2 = rng.normal(size=(rows_n, 512)).astype(np.float32)
+    t1a, t1b, t2a, t2b = layer(512, 512, 0, 128, 1), layer(128, 128, 0, 3, 0), layer(512, 512, 0, 128, 1), layer(128, 128, 0, 32, 0)
+    o1 = torch.empty((rows_n, 3), device="cuda")
+    o2 = torch.empty((rows_n, 32), device="cuda")
+    towers = [[(dev(t1a[0]), 0, dev(t1a[1]), 512, 128, 1, None, 0), (dev(t1b[0]), 0, dev(t1b[1]), 128, 3, 0, o1, 0)],
+              [(dev(t2a[0]), 0, dev(t2a[1]), 512, 128, 1, None, 0), (dev(t2b[0]), 0, dev(t2b[1]), 128, 32, 0, o2, 0)]]
+    assert fused.mlp_rows_eligible(512, towers)
+    fused.mlp_rows(dev(x2), 0, towers)
+    r1 = oracle_ops.linear(oracle_ops.linear(x2, t1a[0][:, :128], t1a[1], 1), t1b[0][:, :3], t1b[1], 0)
+    r2 = oracle_ops.linear(oracle_ops.linear(x2, t2a[0][:, :128], t2a[1], 1), t2b[0][:, :32], t2b[1], 0)
+    np.testing.assert_array_equal(o1.cpu().numpy(), r1)
+    np.testing.assert_array_equal(o2.cpu().numpy(), r2)
