@@ -361,9 +361,12 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   hipLaunchKernelGGL(coop_keys_kernel, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, keys_in, vals_in, exch,
                      2 * parts * kSlotWords, err);
   size_t cub = L.cub_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub, keys_in, keys_out, vals_in, vals_out, (unsigned)((size_t)b * n), 0,
-                                         20 + scene_bits(b), stream) != hipSuccess)
-    return det6d_check_launch("det6d_fps (cooperative: sort)") == DET6D_OK ? DET6D_ELAUNCH : DET6D_ELAUNCH;
+  const hipError_t sort_rc = hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub, keys_in, keys_out, vals_in, vals_out,
+                                                                (unsigned)((size_t)b * n), 0, 20 + scene_bits(b), stream);
+  if (sort_rc != hipSuccess) {
+    det6d_set_error("det6d_fps (cooperative: radix sort)", sort_rc);
+    return DET6D_ELAUNCH;
+  }
   const long long groups = (long long)b * n / 16;
   hipLaunchKernelGGL(coop_group_order_kernel, dim3((unsigned)((groups + 511) / 512)), dim3(512), 0, stream, groups, n, log2s, vals_out);
   const int grid = 8 * parts * ((b + 7) / 8);
