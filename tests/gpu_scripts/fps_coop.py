@@ -23,6 +23,11 @@ def check(xyz, m, tag):
 
 allok = True
 rng = np.random.default_rng(0)
+if os.environ.get('DET6D_FPS_COOP') == '0':      # the memory-resident fallback: two short cases
+    allok &= check(make_batch(31, 2, 65536, dup_frac=0.1)[..., :3], 600, 'fallback scenes 2 x 65536')
+    allok &= check(make_batch(33, 1, 32768, dup_frac=0.3)[..., :3], 400, 'fallback scenes 1 x 32768')
+    print('ALL', allok)
+    sys.exit(0)
 allok &= check(make_batch(31, 3, 65536, dup_frac=0.1)[..., :3], 4096, 'scenes 3 x 65536')
 allok &= check(make_batch(32, 9, 65536, tilt=True)[..., :3], 1024, 'scenes 9 x 65536 (two dispatch groups)')
 allok &= check(make_batch(33, 2, 32768, dup_frac=0.3)[..., :3], 2048, 'scenes 2 x 32768 (two parts)')

@@ -234,12 +234,21 @@ def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, sm
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("env", [{'DET6D_DENSE_ROWS': '1'}, {'DET6D_COMPACT_NO_CHAIN': '1'}, {'DET6D_COMPACT_SPLIT': '0'}, {'DET6D_COMPACT_SMIN': '4'}, {'DET6D_COMPACT_SPLIT': '1'}])
-def test_model_parity_on_the_other_row_paths(env):
-    """the whole-model bit-exact tests run on compact rows with the chain kernels by default; rerun a subset on the
-    reference's dense row space and on the three-GEMM compact route (switches are read at import: child process)"""
+@pytest.mark.parametrize("env,select", [
+    ({'DET6D_DENSE_ROWS': '1'}, 'tiny or sloped or three_class'), ({'DET6D_COMPACT_NO_CHAIN': '1'}, 'tiny or sloped or three_class'),
+    ({'DET6D_COMPACT_SPLIT': '0'}, 'tiny or sloped or three_class'), ({'DET6D_COMPACT_SMIN': '4'}, 'tiny or sloped or three_class'),
+    ({'DET6D_COMPACT_SPLIT': '1'}, 'tiny or sloped or three_class'),
+    # the round-1 routes behind the round-2 kernels: gathered first-layer GEMM, three launches per wide group, one launch per
+    # plain layer (alone and on dense rows), and only the first sampler hoisted out of the captured passes
+    ({'DET6D_NO_EXPAND': '1'}, 'sloped or three_class'), ({'DET6D_NO_GROUP_KERNEL': '1'}, 'sloped or three_class'),
+    ({'DET6D_NO_ROWS_KERNEL': '1'}, 'tiny or sloped'), ({'DET6D_NO_GROUP_KERNEL': '1', 'DET6D_DENSE_ROWS': '1'}, 'sloped'),
+    ({'DET6D_NO_EXPAND': '1', 'DET6D_DENSE_ROWS': '1'}, 'sloped'),
+    ({'DET6D_NO_HOIST': '1'}, 'pass_group or two_stage or graph_replay')])
+def test_model_parity_on_the_other_row_paths(env, select):
+    """the whole-model bit-exact tests run on compact rows with the fused kernels by default; rerun subsets on the
+    reference's dense row space and on every alternative route (switches are read at import: child process)"""
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_model_gpu.py'), '-q', '-x', '-m', 'gpu',
-                          '-k', 'tiny or sloped or three_class'], env=dict(os.environ, **env), cwd=ROOT, capture_output=True,
+                          '-k', select], env=dict(os.environ, **env), cwd=ROOT, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout

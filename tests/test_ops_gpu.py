@@ -413,6 +413,10 @@ def test_cooperative_sampler_for_large_scenes():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout, out.stdout
     print(out.stdout)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py")], capture_output=True, text=True,
+                         timeout=900, env=dict(os.environ, DET6D_FPS_COOP="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALL True" in out.stdout and "fallback" in out.stdout, out.stdout
 
 
 def test_ball_query_grid_adversarial(ext, oracle_ops):
