@@ -129,3 +129,26 @@ def test_hoist_plan_is_the_input_only_sampler_chain():
         (0, 0, None, 0, 16384, 4096, 0, 0, True),
         (1, 1, (0, 0), 0, 4096, 512, 512, 0, True),
         (2, 1, (1, 1), 0, 512, 256, 256, 512, False)]
+
+
+def test_ray_cast_scene_generator():
+    """de6d_amd/synthetic.py: beam_scene is deterministic, returns exactly n in-range points through the reference's
+    near / far sampling rule, and its density falls with range like a spinning LiDAR's (what makes the ball fill realistic)"""
+    from de6d_amd.synthetic import beam_scene, sample_points_rule, points_tensor, beam_batch
+    a, b = beam_scene(7, 16384), beam_scene(7, 16384)
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (16384, 4) and a.dtype == np.float32 and np.isfinite(a).all()
+    assert a[:, 0].min() >= 0 and a[:, 0].max() <= 70.4 and np.abs(a[:, 1]).max() <= 40 and (a[:, 3] >= 0).all() and (a[:, 3] <= 1).all()
+    d = np.linalg.norm(a[:, :3], axis=1)
+    near, mid = (d < 15).sum(), ((d >= 15) & (d < 30)).sum()
+    assert near > 2 * mid > 0                                     # range-dependent density
+    assert not np.array_equal(a, beam_scene(8, 16384))
+    # the sampling rule: far points (>= 40 m) all survive a down-sampling, short clouds are padded with duplicates
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.uniform(0, 30, (5000, 4)), np.concatenate([rng.uniform(45, 60, (300, 1)), rng.uniform(-5, 5, (300, 3))], 1)]).astype(np.float32)
+    out = sample_points_rule(pts, 2000, np.random.default_rng(1))
+    assert out.shape == (2000, 4) and (np.linalg.norm(out[:, :3], axis=1) >= 40).sum() == 300
+    short = sample_points_rule(pts[:100], 256, np.random.default_rng(2))
+    assert short.shape == (256, 4) and len(np.unique(short, axis=0)) == 100
+    flat = points_tensor(beam_batch(3, 2, 2048))
+    assert flat.shape == (4096, 5) and (flat[:2048, 0] == 0).all() and (flat[2048:, 0] == 1).all()
