@@ -145,7 +145,7 @@ def test_ray_cast_scene_generator():
     assert not np.array_equal(a, beam_scene(8, 16384))
     # the sampling rule: far points (>= 40 m) all survive a down-sampling, short clouds are padded with duplicates
     rng = np.random.default_rng(0)
-    pts = np.concatenate([rng.uniform(0, 30, (5000, 4)), np.concatenate([rng.uniform(45, 60, (300, 1)), rng.uniform(-5, 5, (300, 3))], 1)]).astype(np.float32)
+    pts = np.concatenate([rng.uniform(0, 20, (5000, 4)), np.concatenate([rng.uniform(45, 60, (300, 1)), rng.uniform(-5, 5, (300, 3))], 1)]).astype(np.float32)
     out = sample_points_rule(pts, 2000, np.random.default_rng(1))
     assert out.shape == (2000, 4) and (np.linalg.norm(out[:, :3], axis=1) >= 40).sum() == 300
     short = sample_points_rule(pts[:100], 256, np.random.default_rng(2))
