@@ -723,6 +723,98 @@ ORACLE_API int det6d_oracle_linear(const det6d_linear_args *g) {
   return 0;
 }
 
+/* det6d_group_expand (csrc/expand.hip), restated LITERALLY: the first layer of a grouped MLP from the per-point partial
+ * sums P (the chain over the feature columns, one det6d_oracle_linear over the points with the coordinate rows of W zeroed):
+ *   out[r][c] = act(fma(dz, W[2][c], fma(dy, W[1][c], fma(dx, W[0][c], P[p(r)][pcol0 + c]))) + shift[c]), [c1, ldo) zero.
+ * tests/test_oracle_props.py checks on the CPU that this IS det6d_oracle_linear in the gathered modes (chain_k order). */
+ORACLE_API int det6d_oracle_group_expand(int rows, int c1, const float *p, int ldp, int pcol0, const float *w, int ldw,
+                                         const float *shift, int act, const float *pts, int ldpts, const float *ctr, int ldctr,
+                                         const int *idx, int n, int m, int ns, const int *hdr, const int *crow_p,
+                                         const int *crow_c, float *out, int ldo) {
+  const int live = hdr ? hdr[0] : rows;
+  for (int r = 0; r < live; ++r) {
+    float *o = out + (size_t)r * ldo;
+    for (int c = 0; c < ldo; ++c) o[c] = 0.f;
+    long long prow;
+    int cj;
+    if (hdr) {
+      const int tag = crow_c[r];
+      if (tag < 0) continue;                       /* alignment row */
+      cj = tag & 0x1fffffff;
+      prow = crow_p[r];
+    } else {
+      cj = r / ns;
+      prow = (long long)(cj / m) * n + idx[r];
+    }
+    const float *pt = pts + prow * ldpts, *ce = ctr + (size_t)cj * ldctr;
+    const float dx = pt[0] - ce[0], dy = pt[1] - ce[1], dz = pt[2] - ce[2];
+    for (int c = 0; c < c1; ++c) {
+      float v = D6_FMA(dz, w[2 * (size_t)ldw + c], D6_FMA(dy, w[ldw + c], D6_FMA(dx, w[c], p[prow * ldp + pcol0 + c])));
+      v = shift ? v + shift[c] : v;
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      o[c] = v;
+    }
+  }
+  return 0;
+}
+
+/* det6d_mlp_group3 (csrc/mlp_group.hip): by definition expand -> linear -> linear(pool) */
+ORACLE_API int det6d_oracle_mlp_group3(int rows, const float *p, int ldp, int pcol0, const float *w1, int ldw1, const float *s1, int c1,
+                                       const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3, const float *s3,
+                                       int c3, const float *pts, int ldpts, const float *ctr, int ldctr, const int *idx, int n, int m,
+                                       int ns, const int *cnt, const int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
+                                       int col0) {
+  float *h1 = (float *)calloc((size_t)rows * c1 + 1, sizeof(float));
+  float *h2 = (float *)calloc((size_t)rows * c2 + 1, sizeof(float));
+  det6d_oracle_group_expand(rows, c1, p, ldp, pcol0, w1, ldw1, s1, 1, pts, ldpts, ctr, ldctr, idx, n, m, ns, hdr, crow_p, crow_c, h1, c1);
+  det6d_linear_args g;
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = rows; g.k = c1; g.ncols = c2; g.a = h1; g.lda = c1; g.w = w2; g.ldw = ldw2; g.shift = s2;
+  g.act = 1; g.y = h2; g.ldy = c2; g.hdr = hdr;
+  det6d_oracle_linear(&g);
+  memset(&g, 0, sizeof(g));
+  g.mode = 0; g.rows = rows; g.k = c2; g.ncols = c3; g.a = h2; g.lda = c2; g.w = w3; g.ldw = ldw3; g.shift = s3;
+  g.act = 1; g.y = y; g.ldy = ldy; g.col0 = col0;
+  if (hdr) { g.pool = -1; g.hdr = hdr; g.crow_c = crow_c; } else { g.pool = ns; g.cnt = cnt; }
+  const int rc = det6d_oracle_linear(&g);
+  free(h1); free(h2);
+  return rc;
+}
+
+/* det6d_mlp_rows (csrc/mlp_rows.hip): by definition one det6d_oracle_linear per layer */
+typedef struct det6d_rows_layer {
+  const float *w; int ldw; int wrow0;
+  const float *shift;
+  int k, n, act;
+  float *out; int ldo; int ocol0;
+} det6d_rows_layer;
+ORACLE_API int det6d_oracle_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
+                                     const det6d_rows_layer *layers) {
+  int off = 0;
+  for (int c = 0; c < nchains; ++c) {
+    const float *in = x + xcol0;
+    int ldin = ldx;
+    float *prev = NULL;
+    for (int l = 0; l < nlayers[c]; ++l) {
+      const det6d_rows_layer *L = &layers[off + l];
+      float *h = (float *)calloc((size_t)rows * L->n + 1, sizeof(float));
+      det6d_linear_args g;
+      memset(&g, 0, sizeof(g));
+      g.mode = 0; g.rows = rows; g.k = L->k; g.ncols = L->n; g.a = in; g.lda = ldin; g.w = L->w + (size_t)L->wrow0 * L->ldw;
+      g.ldw = L->ldw; g.shift = L->shift; g.act = L->act; g.y = h; g.ldy = L->n;
+      det6d_oracle_linear(&g);
+      if (L->out)
+        for (int r = 0; r < rows; ++r)
+          for (int j = 0; j < L->n; ++j) L->out[(size_t)r * L->ldo + L->ocol0 + j] = h[(size_t)r * L->n + j];
+      free(prev);
+      prev = h; in = h; ldin = L->n;
+    }
+    free(prev);
+    off += nlayers[c];
+  }
+  return 0;
+}
+
 /* fused narrow-MLP entry: by definition the three-call sequence */
 ORACLE_API int det6d_oracle_mlp_chain3(int rows, int n, int m, int ns, const float *a, int lda, const int *idx,
                                        const float *ctr, int ldctr, const int *cnt, const float *w1, int ldw1,

@@ -243,6 +243,29 @@ def compact_groups(cnt, idx, n, smin=1, split=1):
     return hdr, crow_p, crow_c
 
 
+def group_expand(p, pcol0, w, shift, act, c1, rows_pts, ctr, ldo, idx=None, lists=None):
+    """first layer of a grouped MLP from per-point partial sums (csrc/expand.hip, restated literally): dense rows
+    (idx (B,m,ns)) or a compact list (hdr, crow_p, crow_c); returns (rows, ldo)"""
+    p, w, shift, pts, ctr = _f(p), _f(w), _f(shift), _f(rows_pts), _f(ctr)
+    if lists is not None:
+        hdr, crow_p, crow_c = lists
+        rows = len(crow_p)
+        out = np.full((rows, ldo), -3.0, np.float32)
+        rc = lib().det6d_oracle_group_expand(rows, c1, _pf(p), p.shape[-1], pcol0, _pf(w), w.shape[1], _pf(shift), act, _pf(pts),
+                                             pts.shape[-1], _pf(ctr), ctr.shape[-1], None, 0, 0, 0, _pi(hdr), _pi(crow_p), _pi(crow_c),
+                                             _pf(out), ldo)
+    else:
+        idx = _i(idx)
+        b, m, ns = idx.shape
+        rows = b * m * ns
+        out = np.full((rows, ldo), -3.0, np.float32)
+        rc = lib().det6d_oracle_group_expand(rows, c1, _pf(p), p.shape[-1], pcol0, _pf(w), w.shape[1], _pf(shift), act, _pf(pts),
+                                             pts.shape[-1], _pf(ctr), ctr.shape[-1], _pi(idx), pts.shape[1], m, ns, None, None, None,
+                                             _pf(out), ldo)
+    assert rc == 0
+    return out
+
+
 def mlp_chain3_compact(rows_pts, lists, ctr, layers, out, col0=0):
     """three pointwise layers + max over every centre's rows on a compact list (hdr, crow_p, crow_c);
     layers = [(W, shift)] x 3 with the true widths; out must be zeroed where centres have several parts"""

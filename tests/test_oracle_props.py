@@ -165,3 +165,43 @@ def test_compact_rows_equal_dense_rows(oracle_ops, smin, split):
     assert lists[0][8] == np.minimum(cnt, ns).sum() and lists[0][0] < b * m * ns
     compact = oracle_ops.mlp_chain3_compact(rows, lists, ctr, layers, np.zeros((b * m, widths[2]), np.float32))
     np.testing.assert_array_equal(compact, dense)
+
+
+@pytest.mark.parametrize("lda,c1", [(8, 32), (68, 64), (260, 256)])
+def test_first_layer_from_per_point_sums_is_the_gathered_chain(oracle_ops, lda, c1):
+    """The chain order of gathered rows (features first, relative coordinates last: chain_k) makes the feature part of a
+    grouped MLP's first layer a function of the point alone.  On the CPU, bit for bit: one plain layer over the POINTS
+    with the coordinate rows of W zeroed, then three FMAs per grouped output (det6d_oracle_group_expand = csrc/expand.hip
+    restated) == det6d_oracle_linear over the gathered rows — dense rows and compact lists."""
+    rng = np.random.default_rng(lda)
+    b, n, m, ns = 2, 300, 40, 16
+    rows = rng.normal(size=(b, n, lda)).astype(np.float32)
+    rows[..., lda - 1] = 0.0
+    ctr = np.ascontiguousarray(rows[:, :m, :3] + 0.1 * rng.normal(size=(b, m, 3)).astype(np.float32))
+    w = (0.2 * rng.normal(size=(lda, c1))).astype(np.float32)
+    shift = rng.normal(size=(c1,)).astype(np.float32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    for bi in range(b):
+        for j in range(m):
+            idx[bi, j] = np.resize(idx[bi, j, :max(int(cnt[bi, j]), 1)], ns)
+    want = oracle_ops.linear(rows, w, shift, 1, idx=idx, ctr=ctr)                      # the gathered first layer
+    wz = w.copy()
+    wz[:3] = 0.0
+    p = oracle_ops.linear(rows.reshape(b * n, lda), wz, None, 0)                       # per-point sums
+    got = oracle_ops.group_expand(p, 0, w, shift, 1, c1, rows, ctr, c1 + 4, idx=idx)
+    np.testing.assert_array_equal(got[:, :c1], want)
+    assert (got[:, c1:] == 0).all()
+    lists = oracle_ops.compact_groups(cnt, idx, n)
+    gotc = oracle_ops.group_expand(p, 0, w, shift, 1, c1, rows, ctr, c1, lists=lists)
+    hdr, crow_p, crow_c = lists
+    live = int(hdr[0])
+    for r in range(live):
+        tag = int(crow_c[r])
+        if tag < 0:
+            assert (gotc[r] == 0).all()
+            continue
+        cj, prow = tag & 0x1fffffff, int(crow_p[r])
+        # the dense row of the same (centre, point) pair
+        slot = int(np.where(idx.reshape(b * m, ns)[cj] + (cj // m) * n == prow)[0][0])
+        np.testing.assert_array_equal(gotc[r], want[cj * ns + slot])
