@@ -15,16 +15,23 @@ region.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Timing: the pipeline holds up to 32 passes (16 in their GEMM stage + 4 prefetched sampler groups of 4), so a
+A STEP is one batch of --batch (8) scenes.  The pipeline coalesces --merge consecutive batches into one PASS (default:
+4 batches = 32 scenes; every kernel of the path works scene by scene, so a scene's result does not depend on what
+shares its pass, and the larger launches fill the chip better: +12 % over one pass per batch, `--merge 1`).
+
+Timing: the pipeline holds 20 passes (16 in their GEMM stage + 4 whose sampler stage runs ahead), i.e. 80 steps, so a
 sync-bracketed run of K steps is mostly pipeline fill + drain when K is small.  `value` is therefore measured
 over STEADY-STATE WINDOWS: one continuous stream of steps is issued (a pre-roll that fills the pipeline and lets the
 clocks settle, --warmup steps, the windows, a tail that keeps the pipeline full), with barrier + synchronize before
-and after the stream; a window runs from the finalisation of step s to the finalisation of step s + K — exactly K
-steps are finalised (detections of every scene materialised) inside it — and `value` is the MEDIAN of 17 such
-windows starting on consecutive group boundaries (passes complete in bursts: a single window of K = 20 is +-17 % noisy).  The sync-bracketed time of K steps on an
-empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the timed region
-every pass's last result is compared with an eager pass over the same batch (`selfcheck`); a mismatch exits
-non-zero.
+and after the stream.  Every pass leaves a timing event behind its last kernel; step s counts as DELIVERED at the
+device time at which every step <= s is complete (passes run on different streams and may finish out of order: this
+is what an in-order consumer sees).  A window runs from the delivery of step s to the delivery of step s + K — exactly
+K steps are delivered inside it — and `value` is K x batch over the MEAN of the windows starting on consecutive pass
+boundaries over >= 768 steps of the stream (a single window of K = 20 steps is 5 passes out of 16 in flight: +-30 %
+noisy, and its median is quantised; the mean window is the steady-state time of K steps).  The sync-bracketed time of
+K steps on an empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the
+timed region every pass's last result is compared with ONE-BATCH eager passes over the same batches (`selfcheck`); a
+mismatch exits non-zero.
 
 N > 1: one process per GPU, scenes sharded (weak scaling, 8 scenes per GPU per step), no collective on the data
 path; RCCL is used only for the barrier and the max-over-ranks of the window time.  Without torchrun
@@ -183,7 +190,7 @@ def input_producer_rate(cfg, batch, n_raw=120000):
             "frac": round(alg / sec / 8e12, 4)}
 
 
-def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000):
+def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000, group=4, n_main=16, prefetch=4):
     """raw frames -> annotations: det6d_prepare_points (f1) -> captured Det6D passes -> det6d_kitti_annos + one
     D2H + host dictionaries (f2) through the same two-stage pipeline as the headline run; raw frames resident in HBM"""
     from de6d_amd.ops import fused as F
@@ -200,8 +207,8 @@ def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000):
                          'Tr_velo2cam': np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)})
     meta = {'calib': [calib] * batch, 'image_shape': np.tile(np.array([[375, 1242]], np.int32), (batch, 1)),
             'frame_id': ['%06d' % i for i in range(batch)]}
-    pipe = ScenePipeline(model, batch, n, n_main=16, group=4, prefetch=4, sampler_streams=6,
-                         main_streams=MAIN_STREAMS[:16] or None, samplers=SAMPLER_STREAMS[:6] or None)
+    pipe = ScenePipeline(model, batch, n, n_main=n_main, group=group, prefetch=prefetch, sampler_streams=6,
+                         main_streams=MAIN_STREAMS[:n_main] or None, samplers=SAMPLER_STREAMS[:6] or None)
     scratch = {}
     for r in pipe.passes:
         scratch[id(r)] = (torch.empty((int(F.L.lib().det6d_prepare_points_workspace_bytes(batch, batch * n_raw)),), dtype=torch.uint8, device='cuda'),
@@ -217,14 +224,15 @@ def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000):
     def consume(step, r, preds):
         annos[0] += len(KittiDataset.generate_prediction_dicts(meta, preds, cfg.CLASS_NAMES))
 
-    pipe.run(32, feed=produce, on_done=consume)
+    steps = max(8, steps * 8 // batch)
+    pipe.run(len(pipe.passes) + 4, feed=produce, on_done=consume)
     torch.cuda.synchronize()
     annos[0] = 0
     t0 = time.perf_counter()
     pipe.run(steps, feed=produce, on_done=consume)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"scenes_per_s": round(annos[0] / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3), "steps": steps,
+    return {"scenes_per_s": round(annos[0] / dt, 1), "ms_per_pass": round(dt / steps * 1e3, 3), "passes": steps, "scenes_per_pass": batch,
             "timing": "sync-bracketed (fill + drain included)",
             "stages": "raw %d-pt frames (HBM) -> prepare_points -> Det6D passes -> kitti_annos -> annotation dicts (host)" % n_raw}
 
@@ -273,7 +281,8 @@ def family_saturated(replay, n_streams=16, reps=24, streams=None):
 
 def linear_roofline(model, points, batch, flops_per_scene, streams=None):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel + the register chain kernels: the
-    SA / head MLP GEMMs) measured live with HIP events on the launch stream over one step.
+    SA / head MLP GEMMs) measured live with HIP events on the launch stream over one PASS (`batch` scenes: the launches
+    the pipeline issues, i.e. --merge batches of 8 scenes per launch).
 
     The grouped MLPs run on compact row lists (csrc/compact.hip): rows that only repeat another row of the same
     centre (the reference's padding of partly filled balls) are not evaluated.  Three flop counts are reported:
@@ -324,10 +333,10 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": os.path.basename(pmc[-1]) if pmc and traffic else None,
-            "kernel": "linear_kernel<...> + mlp_chain_*_kernel (fp32 MFMA GEMM family, %d launches/step)" % len(ev),
-            "launches_per_step": len(ev), "avg_launch_us": round(total_ms * 1e3 / max(len(ev), 1), 2),
-            "algorithmic_gflop_per_step": round(useful / 1e9, 2), "issued_gflop_per_step": round(issued / 1e9, 2),
-            "dense_gflop_per_step": round(dense / 1e9, 2),
+            "kernel": "linear_kernel<...> + mlp_chain_*_kernel (fp32 MFMA GEMM family, %d launches/pass)" % len(ev),
+            "launches_per_pass": len(ev), "avg_launch_us": round(total_ms * 1e3 / max(len(ev), 1), 2),
+            "algorithmic_gflop_per_pass": round(useful / 1e9, 2), "issued_gflop_per_pass": round(issued / 1e9, 2),
+            "dense_gflop_per_pass": round(dense / 1e9, 2),
             "issued_tflops": round(issued / (total_ms * 1e-3) / 1e12, 2),
             "dense_equivalent_tflops": round(dense / (total_ms * 1e-3) / 1e12, 2),
             "compact_rows_centres_information_issued": groups,
@@ -346,7 +355,7 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
                 "issued_tflops": round(issued * saturated["passes"] / saturated["seconds"] / 1e12, 2),
                 "streams": saturated["streams"], "replays_per_stream": saturated["replays"],
                 "family_ms_per_pass": round(saturated["seconds"] / saturated["passes"] * 1e3, 4)},
-            "kernel_ms_per_step": round(total_ms, 3)}
+            "kernel_ms_per_pass": round(total_ms, 3)}
 
 
 def child_rate(args, env_extra, extra_args=(), note=""):
@@ -357,7 +366,7 @@ def child_rate(args, env_extra, extra_args=(), note=""):
     env.pop('WORLD_SIZE', None)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
            '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--worker', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
-           '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch),
+           '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch), '--merge', str(args.merge),
            '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + list(extra_args)
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -406,7 +415,10 @@ def selfcheck(model, pipe, b):
     with torch.no_grad():
         for i, r in enumerate(pipe.passes):
             got = r.finalize()
-            want, _ = model({'batch_size': b, 'points': r.points})
+            want = []
+            for j in range(len(got) // b):     # a coalesced pass against ONE-BATCH eager passes over its batches
+                rows = r.points.shape[0] // (len(got) // b)
+                want += model({'batch_size': b, 'points': r.points[j * rows:(j + 1) * rows]})[0]
             torch.cuda.synchronize()
             for sc, (g, w) in enumerate(zip(got, want)):
                 total += 1
@@ -440,7 +452,7 @@ def orchestrate(args):
             ("configs[2] SlopedKITTI Car, batch 8 (sloped scenes, ground-aware pitch branch)",
              ['--cfg', 'slopedkitti_models/det6d_car.yaml', '--tilt']),
             ("configs[3] KITTI 3-class, batch 32 over 8 GPUs = 4 scenes per GPU per step",
-             ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4']),
+             ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4', '--merge', '-1']),
             ("configs[4] 65536 points per scene, batch 64 over 8 GPUs = 8 scenes per GPU per step",
              ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8']),
             ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
@@ -488,15 +500,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--streams', type=int, default=16, help='main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
+    ap.add_argument('--merge', type=int, default=-1, help='consecutive batches coalesced into one pass (ScenePipeline merge); default: as many as make a pass of 32 scenes; 1 = one pass per batch')
+    ap.add_argument('--streams', type=int, default=-1, help='default 16; main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
     ap.add_argument('--prefetch', type=int, default=4, help='groups whose sampler stage is issued ahead of the GEMM stage')
     ap.add_argument('--sampler-streams', type=int, default=6)
-    ap.add_argument('--group', type=int, default=4, help='passes whose first (input-only) sampler runs as one launch; 0 = every pass is a single captured graph')
+    ap.add_argument('--group', type=int, default=-1, help='default 4 (merge 1) / 1 (coalesced passes); passes whose first (input-only) sampler runs as one launch; 0 = every pass is a single captured graph')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
     ap.add_argument('--scene', default='uniform', choices=['uniform', 'beam'], help='synthetic scene generator (de6d_amd/synthetic.py)')
     ap.add_argument('--tilt', action='store_true', help='sloped scenes (BASELINE configs[2])')
-    ap.add_argument('--distinct-batches', type=int, default=8, help='different resident batches the passes cycle through')
-    ap.add_argument('--windows', type=int, default=17, help='overlapping K-step windows in the stream; the median one is the timed region')
+    ap.add_argument('--distinct-batches', type=int, default=16, help='different resident batches the passes cycle through')
+    ap.add_argument('--windows', type=int, default=-1, help='overlapping K-step windows in the stream (default: enough to span 768 steps); their mean is the timed region')
     ap.add_argument('--preroll', type=int, default=-1, help='pre-roll length in pipeline capacities (default 8)')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -505,6 +518,15 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
     ap.add_argument('--h2d', action='store_true', help='PCIe-inclusive variant: every step uploads its batch from pinned host memory (never the headline value)')
     args = ap.parse_args()
+    # pipeline shape: coalesced passes of 32 scenes by default (scripts/r02/gpu_batchsweep.sh, gpu_mergesweep.sh)
+    if args.merge < 0:
+        # the largest number of batches per pass that keeps a pass <= 32 scenes and divides K (a window of K steps is then a
+        # whole number of passes: exactly K steps are delivered inside it)
+        args.merge = 1 if (args.no_graph or args.group == 0) else max(d for d in range(1, max(1, 32 // max(1, args.batch)) + 1) if args.steps % d == 0)
+    if args.group < 0:
+        args.group = 4 if args.merge == 1 else 1
+    if args.streams < 0:
+        args.streams = 16
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))       # nothing above has initialised HIP
@@ -531,12 +553,13 @@ def main():
 
     cfg = load_config(args.cfg)
     model = build_model(cfg, seed=1234, device='cuda')
-    b, n = args.batch, args.points
+    b, n, merge = args.batch, args.points, args.merge
     # every rank its own scenes; the passes in flight cycle through `distinct_batches` different resident batches
-    n_distinct = max(1, args.distinct_batches)
+    n_distinct = max(merge, args.distinct_batches)
     batches_np = [synth_points(1000 + (rank * n_distinct + i) * b, b, n, tilt=args.tilt, scene=args.scene) for i in range(n_distinct)]
     batches = [torch.from_numpy(p).cuda() for p in batches_np]
     pts_np, points = batches_np[0], batches[0]
+    pass_inputs = ScenePipeline.coalesce(batches, merge)     # resident, one tensor per pass (merge batches back to back)
     depth = max(1, args.streams)
     with torch.no_grad():
         model({'batch_size': b, 'points': points})  # fold weights, load code objects
@@ -565,15 +588,15 @@ def main():
             return done
         capacity, k = depth, 1
     elif args.group > 0:
-        host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
+        host_batch = [torch.from_numpy(batches_np[j % n_distinct]).pin_memory() for j in range(merge)] if args.h2d else None
         pipe = ScenePipeline(model, b, n, n_main=depth, group=args.group, prefetch=args.prefetch,
-                             sampler_streams=args.sampler_streams, points=None if args.h2d else batches)
+                             sampler_streams=args.sampler_streams, points=None if args.h2d else pass_inputs, merge=merge)
         MAIN_STREAMS.extend(pipe.main_streams)
         SAMPLER_STREAMS.extend(pipe.sampler_streams)
 
         def run(steps, on_done=None):
             return pipe.run(steps, feed=host_batch, on_done=on_done)
-        capacity, k = len(pipe.passes), pipe.k
+        capacity, k = len(pipe.passes) * merge, pipe.k * merge      # in steps (batches)
     else:
         host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
         runners = [GraphedDet6D(model, b, n, points=None if args.h2d else batches[i % n_distinct]) for i in range(depth)]
@@ -607,32 +630,46 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the timed region: steady-state windows of exactly args.steps finalised steps -----------------------------------
-    # Passes complete in bursts (a group of 4 at a time, groups often in pairs), so ONE window of a few groups is +-17 %
-    # noisy (measured).  The stream therefore carries R overlapping windows, each "finalisation of step s to finalisation
-    # of step s + K" with s on consecutive group boundaries, and the MEDIAN window is the timed region.
+    # Passes complete in bursts, so ONE window of a few passes is +-17..30 % noisy (measured).  The stream therefore
+    # carries R overlapping windows, each "delivery of step s to delivery of step s + K" with s on consecutive group
+    # boundaries, and the MEAN window is the timed region.
     preroll = (args.preroll if args.preroll >= 0 else 8) * capacity   # long enough for clocks / power to settle (~0.2 s)
     preroll += (-(preroll + args.warmup)) % k        # the windows start on group boundaries
-    n_windows = max(1, args.windows)
+    n_windows = args.windows if args.windows > 0 else max(17, -(-768 // k))   # the windows span >= 768 steps of the stream
     tail = capacity
     first = preroll + args.warmup - 1
     last = first + (n_windows - 1) * k + args.steps
     stamps, dets = {}, [0]
+    device_clock = not args.no_graph       # completion times from the device (one timing event per pass) instead of the host
 
     def on_done(step, r, preds):
-        if first <= step <= last:
-            stamps[step] = time.perf_counter()
+        if step <= last:
+            stamps[step] = r.stamp if device_clock else time.perf_counter()
         if first < step <= first + args.steps:
             dets[0] += sum(len(p['pred_scores']) for p in preds)
 
     bracket()
     GraphedDet6D.host_wait_s = 0.0
+    GraphedDet6D.stamp_launches = device_clock
+    origin = torch.cuda.Event(enable_timing=True)
+    origin.record()
     t_stream = time.perf_counter()
     run(last + 1 + tail, on_done)
     bracket()
     t_stream = time.perf_counter() - t_stream
+    GraphedDet6D.stamp_launches = False
     host_wait = GraphedDet6D.host_wait_s
+    if device_clock:
+        # passes run on different streams and may complete out of step order: step s is DELIVERED when every step <= s is
+        # complete (the running maximum of the completion times, what an in-order consumer sees)
+        delivered, t_run = {}, 0.0
+        for s_ in sorted(stamps):
+            t_run = max(t_run, origin.elapsed_time(stamps[s_]) * 1e-3)
+            delivered[s_] = t_run
+        stamps = delivered
     windows = sorted(stamps[first + j * k + args.steps] - stamps[first + j * k] for j in range(n_windows))
-    elapsed_own = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
+    window_median = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
+    elapsed_own = sum(windows) / len(windows)
     elapsed = elapsed_own
 
     # ---- cold: K steps on an EMPTY pipeline, synchronize on both sides (fill + drain inside) ----------------------------
@@ -679,12 +716,18 @@ def main():
                        "cfg": args.cfg, "scenes_per_step_per_gpu": b, "points_per_scene": n, "scene_generator": args.scene,
                        "tilt": args.tilt, "distinct_resident_batches": n_distinct,
                        "timing": "steady-state: one continuous stream of %d steps (%d pre-roll, %d warmup, then the windows, %d tail) "
-                                 "between barrier+synchronize; a window = finalisation of step s to finalisation of step s+%d "
-                                 "(exactly %d steps finalised inside); value = median of %d windows starting on consecutive "
+                                 "between barrier+synchronize; a window = delivery of step s to delivery of step s+%d "
+                                 "(exactly %d steps delivered inside; delivered = every step up to it complete on the device); "
+                                 "value = mean of %d windows starting on consecutive "
                                  "group boundaries" % (last + 1 + tail, preroll, args.warmup, tail, args.steps, args.steps, n_windows),
                        "preroll_steps": preroll, "tail_steps": tail, "windows": n_windows,
-                       "window_ms_min_median_max": [round(windows[0] * 1e3, 3), round(elapsed_own * 1e3, 3), round(windows[-1] * 1e3, 3)],
-                       "streams": depth, "sampler_group": k, "hipgraph": not args.no_graph,
+                       "window_ms_min_median_max": [round(windows[0] * 1e3, 3), round(window_median * 1e3, 3), round(windows[-1] * 1e3, 3)],
+                       "window_ms_mean": round(elapsed_own * 1e3, 3),
+                       "window_clock": "device: completion events of the passes (hipEventElapsedTime)" if device_clock else "host",
+                       "batches_per_pass": merge, "scenes_per_pass": b * merge,
+                       "pass": "a step is one batch of %d scenes; the pipeline coalesces %d consecutive batches into one pass "
+                               "(per-scene results identical to one-batch passes: selfcheck)" % (b, merge),
+                       "streams": depth, "sampler_group": args.group, "hipgraph": not args.no_graph,
                        "input": "pinned host, H2D per step" if args.h2d else "resident in HBM",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "env_knobs": knobs,
                        "parallelism": "scene-sharded x%d, no collective" % world},
@@ -705,13 +748,15 @@ def main():
                                "note": "one batch of %d scenes, one captured graph on one stream, idle chip" % b}
             del lat
         if world == 1 and not args.no_roofline:
-            line["roofline"] = linear_roofline(model, points, b, flops, streams=MAIN_STREAMS)
+            line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS)
+            line["roofline"]["scenes_per_pass"] = b * merge
+            line["roofline"]["steps_per_pass"] = merge
             line["compact_fill"] = compact_fill(model, points, b)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
             line["input_producer"] = input_producer_rate(cfg, b)
             pipe = None  # noqa: F841  (frees the captured graphs before the pipeline leg builds its own)
             torch.cuda.empty_cache()
-            line["pipeline"] = pipeline_rate(cfg, model, b, n)
+            line["pipeline"] = pipeline_rate(cfg, model, b * merge, n, group=args.group, n_main=depth, prefetch=args.prefetch)
         elif world == 1:
             line["compact_fill"] = compact_fill(model, points, b)
         if world == 1 and args.cpu_scenes > 0:

@@ -335,6 +335,11 @@ class GraphedDet6D(object):
         torch.cuda.current_stream().wait_event(self.done)
         if callable(points):          # an input producer filling self.points on the current stream (bench.py pipeline leg)
             points(self)
+        elif isinstance(points, (list, tuple)):     # the batches a coalesced pass is made of, in order
+            at = 0
+            for p in points:
+                self.points[at:at + p.shape[0]].copy_(p, non_blocking=True)
+                at += p.shape[0]
         elif points is not None and points.data_ptr() != self.points.data_ptr():
             self.points.copy_(points, non_blocking=True)
         self.segments[0].replay()
@@ -347,7 +352,16 @@ class GraphedDet6D(object):
                 graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
             self.done.record()
+            self._stamp()
         return self
+
+    #: bench.py sets this to have every launch leave a timing event (`self.stamp`: device-side completion time of the pass)
+    stamp_launches = False
+
+    def _stamp(self):
+        if GraphedDet6D.stamp_launches:
+            self.stamp = torch.cuda.Event(enable_timing=True)
+            self.stamp.record()
 
     def launch(self, points=None):
         self._check_weights()
@@ -360,6 +374,7 @@ class GraphedDet6D(object):
             self.graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
             self.done.record()
+            self._stamp()
         return self
 
     #: seconds the host spent blocked in finalize() (all passes): host-bound pipelines show ~0 here
@@ -468,11 +483,29 @@ class ScenePipeline(object):
     sampler streams, stage 2 (the captured rest of every pass) on `n_main` main streams; a pass is finalised (its
     detections sliced per scene, the only host sync) when the slot it occupies is needed again.
 
-    points: None — every pass owns a static input buffer (`passes[i].points`) the caller fills or copies into;
-            a tensor — every pass reads it; a list of tensors — pass i reads points[i % len(points)]."""
+    merge: consecutive batches coalesced into ONE pass (a pass then holds merge x batch_size scenes).  Every kernel of the
+           path works scene by scene (BN in eval mode, per-scene samplers / ball queries / NMS), so a scene's result does not
+           depend on what shares its pass — bench.py's self-check and tests/test_timed_path_gpu.py compare coalesced passes
+           with one-batch passes bit for bit — but 4x larger launches fill the 256 CUs better (+10 % scenes/s at batch 8).
+           A STEP stays one batch of batch_size scenes: run(steps) and on_done count batches.
+
+    points: None — every pass owns a static input buffer (`passes[i].points`, merge x batch_size scenes) the caller fills
+            or copies into; a tensor — every pass reads it; a list of tensors — pass i reads points[i % len(points)]
+            (each one pass long: see coalesce())."""
+
+    @staticmethod
+    def coalesce(batches, merge):
+        """resident per-batch inputs -> per-pass inputs: pass i = batches i*merge .. i*merge+merge-1 (cyclic) back to back"""
+        if merge <= 1:
+            return list(batches)
+        n_pass = max(1, (len(batches) + merge - 1) // merge)
+        return [torch.cat([batches[(i * merge + j) % len(batches)] for j in range(merge)], 0) for i in range(n_pass)]
 
     def __init__(self, model, batch_size, n_points, n_main=16, group=4, prefetch=4, sampler_streams=6, points=None,
-                 point_width=5, main_streams=None, samplers=None):
+                 point_width=5, main_streams=None, samplers=None, merge=1):
+        self.merge = max(1, int(merge))
+        self.step_scenes = batch_size
+        batch_size = batch_size * self.merge
         self.k = max(1, min(group, n_main))
         self.prefetch = prefetch
         warn_hw_queues(n_main + sampler_streams)
@@ -501,11 +534,13 @@ class ScenePipeline(object):
         torch.cuda.synchronize()
 
     def run(self, steps, feed=None, on_done=None):
-        """`steps` passes through the pipeline; `feed` (host tensor or callable(pass)) supplies the input of a pass whose
-        static buffer is not resident already; on_done(step, pass, pred_dicts) is called in step order as passes are
-        finalised.  Returns the number of passes finalised (== steps)."""
-        k, n_groups, prefetch = self.k, self.n_groups, self.prefetch
-        counts, left = [], steps
+        """`steps` batches through the pipeline (ceil(steps / merge) passes; the last pass of a stream whose length is not a
+        multiple of `merge` runs full and reports its leading batches only); `feed` (host tensor one pass long, list of
+        the batches of a pass, or callable(pass)) supplies the input of a pass whose static buffer is not resident already;
+        on_done(step, pass, pred_dicts of that batch) is called in step order as passes are finalised.  Returns the number
+        of steps finalised (== steps)."""
+        k, n_groups, prefetch, merge, sb = self.k, self.n_groups, self.prefetch, self.merge, self.step_scenes
+        counts, left = [], (steps + merge - 1) // merge
         while left > 0:
             counts.append(min(k, left))
             left -= counts[-1]
@@ -515,9 +550,11 @@ class ScenePipeline(object):
             nonlocal done
             for r in active:
                 preds = r.finalize()
-                if on_done is not None:
-                    on_done(done, r, preds)
-                done += 1
+                for j in range(merge):
+                    if done < steps:
+                        if on_done is not None:
+                            on_done(done, r, preds[j * sb:(j + 1) * sb])
+                        done += 1
 
         for g in range(min(prefetch, len(counts))):
             self.groups[g % n_groups].launch_front(feed, counts[g])

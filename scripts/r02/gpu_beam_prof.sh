@@ -4,6 +4,6 @@ import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('beam', d['value'], 'roof', r['frac'], r['kernel_ms_per_step'], 'alg GF', r['algorithmic_gflop_per_step'], 'sat', r['saturated'])
+        print('beam', d['value'], 'roof', r['frac'], r['kernel_ms_per_pass'], 'alg GF', r['algorithmic_gflop_per_pass'], 'sat', r['saturated'])
         for x in r['launches']: print(x)
 "

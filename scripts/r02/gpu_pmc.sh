@@ -2,7 +2,8 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=24
 tag=${1:-r02b}; out=gpurun_out/pmc_$tag; mkdir -p $out
 STEPS=6; WARM=2
-A="--steps $STEPS --warmup $WARM --streams 1 --no-graph --cpu-scenes 0 --no-roofline --no-legs --preroll 0 --windows 1"
+# --batch 32: the launches of a coalesced pass (bench.py's default pipeline runs 4 batches of 8 scenes per pass)
+A="--steps $STEPS --warmup $WARM --batch ${BATCH:-32} --streams 1 --no-graph --cpu-scenes 0 --no-roofline --no-legs --preroll 0 --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py $A > $out/stats.log 2>&1
 grep '^{' $out/stats.log | cut -c1-300
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; head -8 $f | cut -c1-160
@@ -34,5 +35,5 @@ print(len({r['Dispatch_Id'] for r in csv.DictReader(open(f)) if 'pack_points_ker
 PY
 )
 echo passes=$n
-python3 scripts/pmc_summarise.py $out $n > $out/pmc_summary.json; head -12 $out/pmc_summary.json
+python3 scripts/pmc_summarise.py $out $n ${BATCH:-32} > $out/pmc_summary.json; head -12 $out/pmc_summary.json
 find $out -name "*.csv" -size +3M -delete

@@ -3,5 +3,5 @@ for i in 1 2 3; do python3 bench.py --steps 20 --warmup 5 --no-legs --cpu-scenes
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; print(d['value'], 'roof', r['frac'], r['achieved'], r['kernel_ms_per_step'], r['launches_per_step'], r['saturated'])
+        d=json.loads(l); r=d['roofline']; print(d['value'], 'roof', r['frac'], r['achieved'], r['kernel_ms_per_pass'], r['launches_per_pass'], r['saturated'])
 "; done

@@ -125,6 +125,30 @@ def test_scene_pipeline_stream_equals_eager(oracle_ops):
     step_feed = [i % len(batches) for i in range(n_steps)]
     assert pipe2.run(n_steps, feed=feed, on_done=on_done2) == n_steps
 
+    # coalesced passes (bench.py's default: consecutive batches share a pass): every STEP equals the one-batch eager result
+    for merge, shape in ((2, dict(n_main=8, group=2, prefetch=2)), (4, dict(n_main=6, group=1, prefetch=3))):
+        inputs = ScenePipeline.coalesce(batches, merge)
+        pipe3 = ScenePipeline(model, b, n, sampler_streams=3, points=inputs, merge=merge,
+                              main_streams=pipe.main_streams[:shape['n_main']], samplers=pipe.sampler_streams[:3], **shape)
+        assert all(r.batch_size == b * merge for r in pipe3.passes)
+        which3 = {id(r): i % len(inputs) for i, r in enumerate(pipe3.passes)}
+        slot = {}
+        seen3 = []
+
+        def on_done3(step, r, preds):
+            j = slot.get(id(r), 0)
+            slot[id(r)] = (j + 1) % merge
+            want = eager[(which3[id(r)] * merge + j) % len(batches)]
+            assert len(preds) == b
+            for g, e in zip(preds, want):
+                assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+                assert torch.equal(g['pred_labels'], e['pred_labels'])
+            seen3.append(step)
+        n3 = 10 * merge * pipe3.k + 1      # not a multiple of the pass: the last pass reports its first batch only
+        assert pipe3.run(n3, on_done=on_done3) == n3
+        assert seen3 == list(range(n3))
+        del pipe3
+
 
 def test_device_iou_equals_host_entry():
     """det6d_boxes_iou_bev (device) and det6d_boxes_iou_bev_cpu (the host entry of the reference interface) share
@@ -245,3 +269,4 @@ def test_bench_entry_point_checks_itself():
         assert key in d, key
     assert d['selfcheck'] == 'ok' and d['steps'] == 8 and d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['value'] > 0
     assert 'steady-state' in d['config']['timing'] and d['config']['points_per_scene'] == 16384
+    assert d['config']['batches_per_pass'] == 4 and d['config']['scenes_per_pass'] == 32      # 8 steps = 2 coalesced passes
