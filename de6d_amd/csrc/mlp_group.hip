@@ -96,24 +96,49 @@ __device__ __forceinline__ float bget(const typename BVec<VW>::T &v, int i) {
 // One layer of the tile: acc[j] += X (32 x K, LDS, row stride LDX) x W[:, this wave's columns].  The B fragments come
 // straight from memory, a block (UK k-steps x TN tiles = 32 MFMAs = 2048 matrix cycles) at a time, TWO blocks ahead of
 // their use (L2 latency under load exceeds one block), with one load per VW tiles.
+#ifdef DET6D_EXPERIMENTS
+// timing experiments only (DET6D_GROUP_WHATIF=1, wrong results): every B fragment comes from the first two weight rows, i.e.
+// from the CU's own cache: how much of the kernel's time is the L2 -> CU weight stream?
+__device__ int d6_group_kmul = 1;
+#define D6_KOFF(x) (d6_group_kmul * (x))
+// phase timers of mlp_group_kernel<256, 512, 1024> (100 MHz wall clock as seen by wave 0 of every workgroup, summed):
+// [0] layer 1 incl. its barrier, [1] layer 2 K loop, [2] layer 2 epilogue + barrier, [3] layer 3 K loop, [4] pooling / stores,
+// [5] tiles, [6] whole kernel, [7] workgroups
+__device__ unsigned long long d6_group_phase[8 + 18];   // [8] shader-clock cycles of the kernel (wave 0), [9] .. K-loop wall time of layer 3 by wave (8) and of layer 2 by wave (8), [25] unused
+#define D6_PHASE_DECL const unsigned long long ph_c0 = clock64(); unsigned long long ph_w3 = 0, ph_w2 = 0, ph_wt = 0; unsigned long long ph_t = wall_clock64(), ph_acc[5] = {0, 0, 0, 0, 0}, ph_tiles = 0; const unsigned long long ph_start = ph_t; const bool ph_on = C3 == 1024;
+#define D6_PHASE(i) do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = wall_clock64(); ph_acc[i] += now_ - ph_t; ph_t = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define D6_WAVE_T0 do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); ph_wt = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define D6_WAVE_T1(x) do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); x += wall_clock64() - ph_wt; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define D6_PHASE_END do { if (ph_on && tid == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&d6_group_phase[i_], ph_acc[i_]); atomicAdd(&d6_group_phase[5], ph_tiles); atomicAdd(&d6_group_phase[6], wall_clock64() - ph_start); atomicAdd(&d6_group_phase[7], 1ull); atomicAdd(&d6_group_phase[8], clock64() - ph_c0); } if (ph_on && (tid & 63) == 0) { atomicAdd(&d6_group_phase[9 + (tid >> 6)], ph_w3); atomicAdd(&d6_group_phase[17 + (tid >> 6)], ph_w2); } } while (0)
+#else
+#define D6_PHASE_DECL
+#define D6_PHASE(i)
+#define D6_WAVE_T0
+#define D6_WAVE_T1(x)
+#define D6_PHASE_END
+#define D6_KOFF(x) (x)
+#endif
+
 template <int K, int TN, int LDX>
-__device__ __forceinline__ void group_layer(const float *__restrict__ X, const __amdgpu_buffer_rsrc_t srd, const uint32_t voff,
-                                            const int ldw_bytes, f32x16 (&acc)[TN], const int l31, const int kh) {
-  constexpr int VW = TN >= 4 ? 4 : TN;
-  constexpr int NV = TN / VW;         // loads per k-step
-  constexpr int KS = K / 2;           // k-steps of two
-  constexpr int UK = 32 / TN;         // k-steps per block
-  constexpr int NB = KS / UK;         // blocks
+struct GroupLayer {
+  static constexpr int VW = TN >= 4 ? 4 : TN;
+  static constexpr int NV = TN / VW;         // loads per k-step
+  static constexpr int KS = K / 2;           // k-steps of two
+  static constexpr int UK = 32 / TN;         // k-steps per block
+  static constexpr int NB = KS / UK;         // blocks
   static_assert(KS % UK == 0 && NB >= 2, "block structure");
   typedef typename BVec<VW>::T bvec;
-  bvec b0[UK][NV], b1[UK][NV], b2[UK][NV];
-  auto fetch = [&](bvec (&b)[UK][NV], int blk) {
+  bvec b0[UK][NV], b1[UK][NV], b2[UK][NV];   // three register sets in rotation: while block i computes, blocks i+1 and i+2 are in flight
+
+  __device__ __forceinline__ static void fetch(bvec (&b)[UK][NV], const __amdgpu_buffer_rsrc_t srd, const uint32_t voff,
+                                               const int ldw_bytes, const int blk) {
 #pragma unroll
     for (int u = 0; u < UK; ++u)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) b[u][v] = load_b<VW>(srd, voff, 2 * (blk * UK + u) * ldw_bytes + 128 * VW * v);
-  };
-  auto compute = [&](const bvec (&b)[UK][NV], int blk) {
+      for (int v = 0; v < NV; ++v) b[u][v] = load_b<VW>(srd, voff, D6_KOFF(2 * (blk * UK + u) * ldw_bytes) + 128 * VW * v);
+  }
+  __device__ __forceinline__ static void compute(const bvec (&b)[UK][NV], const float *__restrict__ X, f32x16 (&acc)[TN],
+                                                 const int l31, const int kh, const int blk) {
     float a[UK];
     const float *xa = X + l31 * LDX + 2 * blk * UK + kh;
 #pragma unroll
@@ -122,57 +147,43 @@ __device__ __forceinline__ void group_layer(const float *__restrict__ X, const _
     for (int u = 0; u < UK; ++u)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bget<VW>(b[u][j / VW], j % VW), acc[j], 0, 0, 0);
-  };
-  // three register sets in rotation: while block i computes, blocks i+1 and i+2 are in flight
-  fetch(b0, 0);
-  fetch(b1, 1);
-  int blk = 0;
+  }
+  // the first two blocks of weights: issued BEFORE the phase that produces the layer's input (the first layer's gather,
+  // the second layer's epilogue and the barrier behind it), so that the K loop does not start with an L2 round trip
+  __device__ __forceinline__ void start(const __amdgpu_buffer_rsrc_t srd, const uint32_t voff, const int ldw_bytes) {
+    fetch(b0, srd, voff, ldw_bytes, 0);
+    fetch(b1, srd, voff, ldw_bytes, 1);
+  }
+  // acc[j] += X (32 x K, LDS) x W[:, this wave's columns].  Every fetch is unconditional (past the end it re-reads the
+  // last block): behind a conditional fetch the compiler's s_waitcnt vmcnt accounting assumes the shorter queue and drains
+  // the ring.
+  __device__ __forceinline__ void run(const float *__restrict__ X, const __amdgpu_buffer_rsrc_t srd, const uint32_t voff,
+                                      const int ldw_bytes, f32x16 (&acc)[TN], const int l31, const int kh) {
+    auto clamp = [](int blk) { return blk < NB ? blk : NB - 1; };
+    int blk = 0;
 #pragma unroll 1
-  for (; blk + 3 <= NB; blk += 3) {
-    if (blk + 2 < NB) fetch(b2, blk + 2);
-    compute(b0, blk);
-    if (blk + 3 < NB) fetch(b0, blk + 3);
-    compute(b1, blk + 1);
-    if (blk + 4 < NB) fetch(b1, blk + 4);
-    compute(b2, blk + 2);
+    for (; blk + 3 <= NB; blk += 3) {
+      fetch(b2, srd, voff, ldw_bytes, blk + 2);
+      compute(b0, X, acc, l31, kh, blk);
+      fetch(b0, srd, voff, ldw_bytes, clamp(blk + 3));
+      compute(b1, X, acc, l31, kh, blk + 1);
+      fetch(b1, srd, voff, ldw_bytes, clamp(blk + 4));
+      compute(b2, X, acc, l31, kh, blk + 2);
+    }
+    if (blk < NB) {             // NB mod 3 == 1 or 2 (NB is a power of two)
+      compute(b0, X, acc, l31, kh, blk);
+      if (blk + 1 < NB) compute(b1, X, acc, l31, kh, blk + 1);
+    }
   }
-  if (blk < NB) {             // NB mod 3 == 1 or 2 (NB is a power of two)
-    if (blk + 2 < NB) fetch(b2, blk + 2);
-    compute(b0, blk);
-    if (blk + 1 < NB) compute(b1, blk + 1);
-  }
-}
+};
 
-template <int C1, int C2, int C3, bool COMPACT, int NW>
-__global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
-  constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
-  constexpr int TN2 = C2 / (32 * NW), TN3 = C3 / (32 * NW);     // accumulator tiles per wave: a wave owns 1 / NW of every layer's columns
-  static_assert(TN2 >= 1 && TN3 >= 1, "every wave needs at least one 32-column tile per layer");
-  extern __shared__ float lds[];
-  float *X1 = lds;
-  float *X2 = lds + 32 * LD1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
-  const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
-  if ((int)blockIdx.x >= live_tiles) return;
-  int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
-  if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
-
-  const __amdgpu_buffer_rsrc_t srd2 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w2, 0, 0xffffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w3, 0, 0xffffffff, 0x00020000);
-  const uint32_t voff2 = (uint32_t)(kh * g.ldw2 + wave * (C2 / NW) + tile_col<TN2>(0, l31)) * 4u;
-  const uint32_t voff3 = (uint32_t)(kh * g.ldw3 + wave * (C3 / NW) + tile_col<TN3>(0, l31)) * 4u;
-  float sh2[TN2], sh3[TN3];
-#pragma unroll
-  for (int j = 0; j < TN2; ++j) sh2[j] = g.s2[wave * (C2 / NW) + tile_col<TN2>(j, l31)];
-#pragma unroll
-  for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / NW) + tile_col<TN3>(j, l31)];
-
-  // layer 1 (expand): thread (row = tid / 8, q = tid % 8) produces columns 4q + 32 i of its row
-  constexpr int EPR = 2 * NW;                     // threads per row in the expand phase
+// ---- layer 1 of a 32-row tile (expand.hip's arithmetic): EPR threads per row, thread (row = tid / EPR, q = tid % EPR)
+// produces columns 4q + 4 EPR i of its row:
+// X1[row][c] = relu(fma(dz, W1[2][c], fma(dy, W1[1][c], fma(dx, W1[0][c], P[p][c]))) + s1[c]) ----
+template <int C1, bool COMPACT, int EPR>
+__device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile, const int tid, float *__restrict__ X1) {
+  constexpr int LD1 = C1 + 1;
   const int erow = tid / EPR, eq = tid % EPR;
-
-  for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
-    // ---- layer 1: X1[row][c] = relu(fma(dz, W1[2][c], fma(dy, W1[1][c], fma(dx, W1[0][c], P[p][c]))) + s1[c]) ----
     {
       const int r = tile * 32 + erow;
       long long prow;
@@ -209,30 +220,14 @@ __global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
         }
       }
     }
-    __syncthreads();
-    // ---- layer 2: X2 = relu(X1 W2 + s2) ----
-    {
-      f32x16 acc[TN2];
-#pragma unroll
-      for (int j = 0; j < TN2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-      group_layer<C1, TN2, LD1>(X1, srd2, voff2, g.ldw2 * 4, acc, l31, kh);
-#pragma unroll
-      for (int j = 0; j < TN2; ++j) {
-        float *xc = X2 + wave * (C2 / NW) + tile_col<TN2>(j, l31);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xc[((e & 3) + 8 * (e >> 2) + 4 * kh) * LD2] = d6_relu(acc[j][e] + sh2[j]);
-      }
-    }
-    __syncthreads();
-    // ---- layer 3 + pooling ----
-    f32x16 acc[TN3];
-#pragma unroll
-    for (int j = 0; j < TN3; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    group_layer<C2, TN3, LD2>(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
+}
+
+// ---- max-pool of the third layer's accumulators over the rows of a centre + shift + ReLU + store (compact rows: class
+// layout of compact.hip, parts of a centre combined with an atomic max; dense rows: nsample 32 / 16 per centre) ----
+template <int TN3, bool COMPACT>
+__device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int tile, f32x16 (&acc)[TN3], const float (&sh3)[TN3],
+                                                 const int colbase, const int l31, const int kh, const int h1, const int h2,
+                                                 const int h3, const int h4, const int h5) {
     if (COMPACT) {
       const int sc = g_class(tile * 32, h1, h2, h3, h4, h5);
       if (sc < 4) {       // classes 1, 2: every accumulator (pair) is a centre part of its own
@@ -241,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
           if (sc == 2 && (e & 1)) continue;
           const int tag = g.crow_c[tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
           if (tag < 0) continue;
-          float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / NW);
+          float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + colbase;
 #pragma unroll
           for (int j = 0; j < TN3; ++j) {
             const float raw = sc == 2 ? d6_vmax(acc[j][e], acc[j][e + 1 < 16 ? e + 1 : e]) : acc[j][e];
@@ -265,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
             if (oc[qq] >= 0)
-              g_store(g.y + (size_t)(oc[qq] & 0x1fffffff) * g.ldy + g.col0 + wave * (C3 / NW) + tile_col<TN3>(j, l31),
+              g_store(g.y + (size_t)(oc[qq] & 0x1fffffff) * g.ldy + g.col0 + colbase + tile_col<TN3>(j, l31),
                       (oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]), oc[qq]);
         }
       }
@@ -281,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
           const float mq = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
           q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
         }
-        float *dst = g.y + g.col0 + wave * (C3 / NW) + tile_col<TN3>(j, l31);
+        float *dst = g.y + g.col0 + colbase + tile_col<TN3>(j, l31);
         if (kh == 0) {
           if (g.ns == 32) {
             const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
@@ -293,9 +288,215 @@ __global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
         }
       }
     }
+}
+
+template <int C1, int C2, int C3, bool COMPACT, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
+  constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
+  constexpr int TN2 = C2 / (32 * NW), TN3 = C3 / (32 * NW);     // accumulator tiles per wave: a wave owns 1 / NW of every layer's columns
+  static_assert(TN2 >= 1 && TN3 >= 1, "every wave needs at least one 32-column tile per layer");
+  extern __shared__ float lds[];
+  float *X1 = lds;
+  float *X2 = lds + 32 * LD1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
+  if ((int)blockIdx.x >= live_tiles) return;
+  int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+  if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
+
+  const __amdgpu_buffer_rsrc_t srd2 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w2, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w3, 0, 0xffffffff, 0x00020000);
+  const uint32_t voff2 = (uint32_t)(kh * g.ldw2 + wave * (C2 / NW) + tile_col<TN2>(0, l31)) * 4u;
+  const uint32_t voff3 = (uint32_t)(kh * g.ldw3 + wave * (C3 / NW) + tile_col<TN3>(0, l31)) * 4u;
+  float sh2[TN2], sh3[TN3];
+#pragma unroll
+  for (int j = 0; j < TN2; ++j) sh2[j] = g.s2[wave * (C2 / NW) + tile_col<TN2>(j, l31)];
+#pragma unroll
+  for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / NW) + tile_col<TN3>(j, l31)];
+
+  D6_PHASE_DECL
+  for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
+#ifdef DET6D_EXPERIMENTS
+    ++ph_tiles;
+#endif
+    GroupLayer<C1, TN2, LD1> second;
+    GroupLayer<C2, TN3, LD2> third;
+    second.start(srd2, voff2, g.ldw2 * 4);
+    group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1);
+    __syncthreads();
+    D6_PHASE(0);
+    // ---- layer 2: X2 = relu(X1 W2 + s2) ----
+    {
+      f32x16 acc[TN2];
+#pragma unroll
+      for (int j = 0; j < TN2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      D6_WAVE_T0;
+      second.run(X1, srd2, voff2, g.ldw2 * 4, acc, l31, kh);
+      third.start(srd3, voff3, g.ldw3 * 4);
+      D6_WAVE_T1(ph_w2);
+      D6_PHASE(1);
+#pragma unroll
+      for (int j = 0; j < TN2; ++j) {
+        float *xc = X2 + wave * (C2 / NW) + tile_col<TN2>(j, l31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xc[((e & 3) + 8 * (e >> 2) + 4 * kh) * LD2] = d6_relu(acc[j][e] + sh2[j]);
+      }
+    }
+    __syncthreads();
+    D6_PHASE(2);
+    // ---- layer 3 + pooling ----
+    f32x16 acc[TN3];
+#pragma unroll
+    for (int j = 0; j < TN3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    D6_WAVE_T0;
+    third.run(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
+    D6_WAVE_T1(ph_w3);
+    D6_PHASE(3);
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / NW), l31, kh, h1, h2, h3, h4, h5);
     // no barrier here: the next tile's layer 1 writes X1, which every wave finished reading before the barrier above;
     // X2 is rewritten only after the next tile's first barrier, which no wave passes before it has left layer 3
+    D6_PHASE(4);
   }
+  D6_PHASE_END;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Streaming form for the widest groups (C2 >= 256): the second layer is produced 128 columns at a time and consumed at once
+// as a K-chunk of the third layer, so a tile keeps 32 x (C1 + 2 x 128) floats in LDS (66 KB for C1 = 256) instead of
+// 32 x (C1 + C2) (99 KB for the head's [256 -> 512 -> 1024] group): TWO workgroups of four waves share a CU, and while one
+// of them gathers its first layer, crosses a barrier or pools and stores, the other keeps the matrix pipes busy.  (Phase
+// timers of the one-workgroup form on the head's wide group: 104 us per tile of which 68 us are matrix cycles; the rest is
+// the first layer's gather, barrier skew and the pooling epilogue, during which a CU with one workgroup idles.)
+// Wave w owns columns [32w, 32w + 32) of every second-layer chunk and the quarter [w C3 / 4, (w + 1) C3 / 4) of the third
+// layer, whose accumulators (C3 / 128 tiles of 32 x 32 = up to 128 registers) stay live across the chunks: every output
+// is still one ascending-k chain (chunks in ascending order), bit-identical to the other forms.
+// B fragments: ring of DEPTH register sets of UK k-steps, DEPTH - 1 blocks ahead of their use.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int K, int TN, int LDX, int UK, int DEPTH>
+__device__ __forceinline__ void stream_layer(const float *__restrict__ X, const __amdgpu_buffer_rsrc_t srd, const uint32_t voff,
+                                             const int ldw_bytes, const int soff0, f32x16 (&acc)[TN], const int l31, const int kh) {
+  constexpr int VW = TN >= 4 ? 4 : TN;
+  constexpr int NV = TN / VW;
+  constexpr int KS = K / 2;
+  constexpr int NB = KS / UK;
+  static_assert(KS % UK == 0 && NB % DEPTH == 0 && NB >= DEPTH, "ring structure");
+  typedef typename BVec<VW>::T bvec;
+  bvec b[DEPTH][UK][NV];
+  auto fetch = [&](bvec (&bs)[UK][NV], int blk) {
+#pragma unroll
+    for (int u = 0; u < UK; ++u)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) bs[u][v] = load_b<VW>(srd, voff, soff0 + D6_KOFF(2 * (blk * UK + u) * ldw_bytes) + 128 * VW * v);
+  };
+  const float *xa = X + l31 * LDX + kh;
+  float a[UK];
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) fetch(b[d], d);
+#pragma unroll
+  for (int u = 0; u < UK; ++u) a[u] = xa[2 * u];
+#pragma unroll 1
+  for (int blk = 0; blk < NB; blk += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int cur = blk + d;
+      // unconditional (the tail re-reads the last block): a conditional fetch makes the compiler's s_waitcnt vmcnt
+      // accounting assume the shorter queue and drain the ring at every step
+      fetch(b[(d + DEPTH - 1) % DEPTH], cur + DEPTH - 1 < NB ? cur + DEPTH - 1 : NB - 1);
+      float an[UK];
+      const int nxt = cur + 1 < NB ? cur + 1 : cur;      // the A fragment of the next block, ahead of this block's MFMAs
+#pragma unroll
+      for (int u = 0; u < UK; ++u) an[u] = xa[2 * (nxt * UK + u)];
+#pragma unroll
+      for (int u = 0; u < UK; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bget<VW>(b[d][u][j / VW], j % VW), acc[j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UK; ++u) a[u] = an[u];
+    }
+  }
+}
+
+template <int C1, int C2, int C3, bool COMPACT>
+__global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArgs g) {
+  constexpr int CH = 128;                          // second-layer columns per chunk = third-layer k per chunk
+  constexpr int NCH = C2 / CH;
+  constexpr int LD1 = C1 + 1, LDY = CH + 1;
+  constexpr int TN3 = C3 / 128;                    // accumulator tiles per wave in the third layer
+  static_assert(C2 % CH == 0 && NCH >= 2 && TN3 >= 2, "chunk structure");
+  extern __shared__ float lds[];
+  float *X1 = lds;
+  float *Y0 = lds + 32 * LD1;
+  float *Y1 = Y0 + 32 * LDY;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
+  if ((int)blockIdx.x >= live_tiles) return;
+  int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+  if (COMPACT) { h1 = g.hdr[1]; h2 = g.hdr[2]; h3 = g.hdr[3]; h4 = g.hdr[4]; h5 = g.hdr[5]; }
+
+  const __amdgpu_buffer_rsrc_t srd2 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w2, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w3, 0, 0xffffffff, 0x00020000);
+  const uint32_t voff2 = (uint32_t)(kh * g.ldw2 + 32 * wave + l31) * 4u;                          // + 128 c columns per chunk
+  const uint32_t voff3 = (uint32_t)(kh * g.ldw3 + wave * (C3 / 4) + tile_col<TN3>(0, l31)) * 4u;   // + 128 c rows per chunk
+  float sh3[TN3];
+#pragma unroll
+  for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / 4) + tile_col<TN3>(j, l31)];
+
+  // one chunk of the second layer: Y[:, 32w .. 32w + 31] = relu(X1 W2[:, 128 c + 32 w ..] + s2)
+  auto second = [&](const int c, float *__restrict__ Y) {
+    const float sh2 = g.s2[CH * c + 32 * wave + l31];
+    f32x16 acc2[1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[0][e] = 0.f;
+    stream_layer<C1, 1, LD1, 8, 4>(X1, srd2, voff2, g.ldw2 * 4, CH * c * 4, acc2, l31, kh);
+    float *yc = Y + 32 * wave + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) yc[((e & 3) + 8 * (e >> 2) + 4 * kh) * LDY] = d6_relu(acc2[0][e] + sh2);
+  };
+
+  for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
+    group_layer1<C1, COMPACT, 8>(g, tile, tid, X1);
+    __syncthreads();
+    f32x16 acc[TN3];
+#pragma unroll
+    for (int j = 0; j < TN3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    second(0, Y0);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      float *Yc = (c & 1) ? Y1 : Y0;
+      float *Yn = (c & 1) ? Y0 : Y1;
+      // third layer, k = 128 c .. 128 c + 127, for all of this wave's columns
+      stream_layer<CH, TN3, LDY, 16 / TN3 >= 1 ? 16 / TN3 : 1, 4>(Yc, srd3, voff3, g.ldw3 * 4, CH * c * g.ldw3 * 4, acc, l31, kh);
+      if (c + 1 < NCH) {
+        second(c + 1, Yn);            // the other buffer: last read in chunk c - 1, a barrier ago
+        __syncthreads();
+      }
+    }
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5);
+    // no barrier here: X1 is rewritten by the next tile's layer 1, every wave is past its last second-layer chunk (the
+    // barrier above); Y0 is rewritten after the next tile's first barrier, Y1 two barriers later
+  }
+}
+
+template <int C1, int C2, int C3, bool COMPACT>
+int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
+  const size_t lds_bytes = sizeof(float) * 32 * (size_t)(C1 + 1 + 2 * 129);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void *)mlp_group_stream_kernel<C1, C2, C3, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_set = true;
+  }
+  int blocks = g.rows / 32;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL((mlp_group_stream_kernel<C1, C2, C3, COMPACT>), dim3(blocks), dim3(256), lds_bytes, stream, g);
+  return det6d_check_launch("det6d_mlp_group3 (streaming)");
 }
 
 template <int C1, int C2, int C3, bool COMPACT, int NW>
@@ -311,11 +512,29 @@ int launch_group(const GroupArgs &g, hipStream_t stream) {
   if (per_cu < 1) per_cu = 1;
   int blocks = g.rows / 32;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+#ifdef DET6D_EXPERIMENTS
+  static const int whatif = det6d_env_int("DET6D_GROUP_WHATIF", 0);
+  static bool whatif_set = false;
+  if (whatif && !whatif_set) {
+    const int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(d6_group_kmul), &zero, sizeof(int));
+    whatif_set = true;
+  }
+#endif
   hipLaunchKernelGGL((mlp_group_kernel<C1, C2, C3, COMPACT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, stream, g);
   return det6d_check_launch("det6d_mlp_group3");
 }
 
 }  // namespace
+
+#ifdef DET6D_EXPERIMENTS
+// timing experiments only: reads and clears the phase timers
+extern "C" __attribute__((visibility("default"))) int det6d_dbg_group_phase(unsigned long long *out_host) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(d6_group_phase), sizeof(unsigned long long) * 26) != hipSuccess) return -1;
+  const unsigned long long zero[26] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(d6_group_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // widths this kernel is built for (Det6D's SA3 and head-SA groups)
 static bool group_widths_ok(int c1, int c2, int c3) {
@@ -354,6 +573,15 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   // waves per 32-row tile: 8 for the head's groups (two waves per SIMD from ONE workgroup: the 99 KB of LDS allow only one
   // workgroup per CU), 4 for the SA3 groups (several workgroups per CU); DET6D_GROUP_WAVES (experiments build) overrides
   static const int nw_env = det6d_env_int("DET6D_GROUP_WAVES", 0);
+  // DET6D_GROUP_STREAM: 1 = the streaming form (two workgroups per CU) for the head's wide group; 2 = also for the
+  // [256 -> 256 -> 512] group; 0 (default) = the one-pass form everywhere.  Same bits; measured within +-1 % of each other
+  // in the pipeline (12.98 vs 12.87 k scenes/s, ray-cast scenes 6.06 vs 6.09 k) once the one-pass form fetched its first
+  // weight blocks ahead of the producing phase, so the simpler form stays the default.
+  static const int stream_form = det6d_switch_int("DET6D_GROUP_STREAM", 0);
+  if (stream_form >= 1 && c1 == 256 && c2 == 512 && c3 == 1024)
+    return compact ? launch_group_stream<256, 512, 1024, true>(g, s) : launch_group_stream<256, 512, 1024, false>(g, s);
+  if (stream_form >= 2 && c1 == 256 && c2 == 256 && c3 == 512)
+    return compact ? launch_group_stream<256, 256, 512, true>(g, s) : launch_group_stream<256, 256, 512, false>(g, s);
 #define D6_GROUP(A, B, C, NWD)                                                                        \
   if (c1 == A && c2 == B && c3 == C) {                                                                \
     if ((nw_env ? nw_env : NWD) == 8 && B >= 256)                                                     \

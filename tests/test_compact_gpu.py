@@ -291,6 +291,20 @@ def test_group_kernel_equals_dense_oracle(oracle_ops, c_in, widths, ns, smin, sp
     np.testing.assert_array_equal(out2.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_group_kernel_other_forms(form):
+    """DET6D_GROUP_STREAM: 0 (default) = one-pass form everywhere; 1 = streaming form (second layer in 128-column chunks, two
+    workgroups per CU) for the head's [256 -> 512 -> 1024] group; 2 = for [256 -> 256 -> 512] as well.  Same bits on every
+    route (the switch is read once per process: child process)."""
+    if os.environ.get('DET6D_GROUP_STREAM') is not None:
+        pytest.skip('already a child')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                          'test_group_kernel_equals_dense_oracle or test_group_kernel_on_degenerate_lists'],
+                         env=dict(os.environ, DET6D_GROUP_STREAM=form), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'passed' in out.stdout
+
+
 @pytest.mark.parametrize("case", ["all_empty", "all_full", "all_single", "one_centre"])
 def test_group_kernel_on_degenerate_lists(oracle_ops, case):
     from de6d_amd.ops import fused
