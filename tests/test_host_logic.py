@@ -152,3 +152,63 @@ def test_ray_cast_scene_generator():
     assert short.shape == (256, 4) and len(np.unique(short, axis=0)) == 100
     flat = points_tensor(beam_batch(3, 2, 2048))
     assert flat.shape == (4096, 5) and (flat[:2048, 0] == 0).all() and (flat[2048:, 0] == 1).all()
+
+
+def test_scene_pipeline_step_accounting_with_coalesced_passes():
+    """ScenePipeline.run counts BATCHES (steps) while its passes hold `merge` batches each: launch order, prefetch distance,
+    on_done once per batch in step order with that batch's slice of the pass, and a stream whose length is not a multiple
+    of `merge` ends with a full pass that reports its leading batches only.  (Fake groups: the choreography is host logic.)"""
+    from de6d_amd.runtime import ScenePipeline
+
+    log = []
+
+    class FakePass(object):
+        def __init__(self, name, scenes):
+            self.name, self.scenes, self.launched = name, scenes, 0
+
+        def finalize(self):
+            return [(self.name, self.launched, i) for i in range(self.scenes)]
+
+    class FakeGroup(object):
+        def __init__(self, g, k, scenes):
+            self.runners = [FakePass((g, j), scenes) for j in range(k)]
+            self.count = k
+
+        def launch_front(self, feed, count):
+            self.count = count
+            log.append(('front', self.runners[0].name[0], count))
+
+        def launch_rest(self):
+            log.append(('rest', self.runners[0].name[0]))
+            for r in self.runners[:self.count]:
+                r.launched += 1
+            return self.runners[:self.count]
+
+    for merge, k, n_groups, prefetch, steps in ((4, 1, 6, 2, 21), (2, 2, 4, 2, 13), (1, 4, 3, 1, 9)):
+        pipe = object.__new__(ScenePipeline)
+        pipe.merge, pipe.step_scenes, pipe.k, pipe.prefetch, pipe.n_groups = merge, 8, k, prefetch, n_groups
+        pipe.groups = [FakeGroup(g, k, 8 * merge) for g in range(n_groups)]
+        del log[:]
+        seen = []
+
+        def on_done(step, r, preds):
+            seen.append((step, r.name, [p[2] for p in preds]))
+        assert pipe.run(steps, on_done=on_done) == steps
+        assert [s for s, _, _ in seen] == list(range(steps))
+        n_pass = -(-steps // merge)
+        for step, name, scenes in seen:
+            p = step // merge                                   # pass in launch order
+            assert name == ((p // k) % n_groups, p % k)
+            assert scenes == list(range((step % merge) * 8, (step % merge + 1) * 8))      # that batch's slice of the pass
+        fronts = [e for e in log if e[0] == 'front']
+        rests = [e for e in log if e[0] == 'rest']
+        assert sum(c for _, _, c in fronts) == n_pass and len(rests) == len(fronts)
+        # a group's sampler stage is issued `prefetch` groups ahead of its GEMM stage
+        first_rest = next(i for i, e in enumerate(log) if e[0] == 'rest')
+        assert sum(1 for e in log[:first_rest] if e[0] == 'front') == min(prefetch + 1, len(fronts))
+
+    batches = [torch.full((6, 5), float(i)) for i in range(5)]
+    merged = ScenePipeline.coalesce(batches, 2)
+    assert len(merged) == 3 and all(m.shape == (12, 5) for m in merged)
+    assert merged[2][:6].eq(4).all() and merged[2][6:].eq(0).all()      # cyclic
+    assert ScenePipeline.coalesce(batches, 1)[3] is batches[3]
