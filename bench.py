@@ -446,6 +446,10 @@ def orchestrate(args):
         line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
                                         note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
                                              "the bound for clouds whose every ball is full")
+        if args.merge > 1:
+            line["one_pass_per_batch"] = child_rate(args, {}, ['--merge', '1', '--group', '4'],
+                                                    note="--merge 1 --group 4: every batch of %d scenes is a pass of its own (the shape of the "
+                                                         "first half of round 2); `value` coalesces %d batches per pass" % (args.batch, args.merge))
         # the other BASELINE.json configurations (per-GPU share) and ray-cast 64-ring LiDAR scenes, same engine, same
         # steps / warmup / timing; parity of each: tests/test_timed_path_gpu.py, tests/test_model_gpu.py
         legs = [
