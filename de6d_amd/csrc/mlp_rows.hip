@@ -4,13 +4,15 @@
 // As separate det6d_linear launches these are 12 of the 24 GEMM-family launches of a pass and each is latency-bound
 // (2 048 .. 32 768 rows, 0.0-0.5 GFLOP, 6-21 us on an idle chip); here a 32-row tile goes through the whole stack with
 // its activations in LDS (row-major, odd stride: conflict-free MFMA A fragments) and the weights read straight from L2
-// into the B fragments, one 16-k-step block ahead — the scheme of mlp_group.hip at run-time widths.
+// into the B fragments, two 16-k-step blocks ahead, the first two requested before the barrier that completes the layer's
+// input — the scheme of mlp_group.hip at run-time widths.
 // Every output is the same ascending-k fma chain as det6d_linear (+ shift, activation): bit-identical.
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4r __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxLayers = 4;
 
@@ -18,6 +20,7 @@ struct RowsArgs {
   int rows;
   const float *x; int ldx; int xcol0; int k0;     // input: columns [xcol0, xcol0 + k0) of x (rows, ldx)
   int width;                                      // LDS row width (max of k0 and the hidden widths)
+  int vec4;                                       // input rows are 16-byte aligned and k0 % 4 == 0
   int nlayers[2];
   det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
 };
@@ -32,14 +35,21 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   const int ntiles_rows = (g.rows + 31) >> 5;
   const int lrow = tid >> 3, lq = tid & 7;
   for (int tile = blockIdx.x; tile < ntiles_rows; tile += gridDim.x) {
-    // ---- input tile -> XA (rows past the end: zeros) ----
+    // ---- input tile -> XA (rows past the end: zeros); 8 threads per row, 16 bytes each where the rows allow it ----
     {
       const int r = tile * 32 + lrow;
       const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0;
       float *dst = XA + lrow * LD;
-      for (int c = lq; c < g.k0; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
+      if (g.vec4) {
+        for (int c = 4 * lq; c < g.k0; c += 32) {
+          const f32x4r v = *reinterpret_cast<const f32x4r *>(src + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[c + e] = r < g.rows ? v[e] : 0.f;
+        }
+      } else {
+        for (int c = lq; c < g.k0; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
+      }
     }
-    __syncthreads();
     for (int l = 0; l < nl; ++l) {
       const det6d_rows_layer &L = g.layers[chain][l];
       const float *X = (l & 1) ? XB : XA;
@@ -50,18 +60,29 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
       const int ldw_bytes = L.ldw * 4;
       const int ncol_tiles = (L.n + 31) >> 5;
       const int nblk = L.k >> 5;                      // blocks of 16 k-steps (k is a multiple of 32)
+      // B fragments: ring of three register sets of 16 k-steps, two blocks ahead of their use.  Every fetch is
+      // unconditional (past the end it re-reads the last block): behind a conditional fetch the compiler's s_waitcnt
+      // vmcnt accounting assumes the shorter queue and drains the ring.  The first two blocks of a wave's first column
+      // tile are requested BEFORE the barrier that completes the layer's input in LDS (weights do not depend on it).
+      float bs[3][16];
+      auto fetch = [&](float (&b)[16], uint32_t voff, int blk) {
+        const int bb = blk < nblk ? blk : nblk - 1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, 2 * (bb * 16 + u) * ldw_bytes, 0));
+      };
+      if (wave < ncol_tiles) {
+        const uint32_t voff0 = (uint32_t)(kh * L.ldw + 32 * wave + l31) * 4u;
+        fetch(bs[0], voff0, 0);
+        fetch(bs[1], voff0, 1);
+      }
+      __syncthreads();
       for (int j = wave; j < ncol_tiles; j += 4) {
         const int col = 32 * j + l31;
         const uint32_t voff = (uint32_t)(kh * L.ldw + col) * 4u;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        float b0[16], b1[16];
-        auto fetch = [&](float (&b)[16], int blk) {
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, 2 * (blk * 16 + u) * ldw_bytes, 0));
-        };
         auto compute = [&](const float (&b)[16], int blk) {
           const float *xa = X + l31 * LD + 32 * blk + kh;
           float a[16];
@@ -70,14 +91,22 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
 #pragma unroll
           for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
         };
-        fetch(b0, 0);
-#pragma unroll 1
-        for (int blk = 0; blk < nblk; blk += 2) {
-          if (blk + 1 < nblk) fetch(b1, blk + 1);
-          compute(b0, blk);
-          if (blk + 2 < nblk) fetch(b0, blk + 2);
-          if (blk + 1 < nblk) compute(b1, blk + 1);
+        if (j != wave) {
+          fetch(bs[0], voff, 0);
+          fetch(bs[1], voff, 1);
         }
+        int blk = 0;
+#pragma unroll 1
+        for (; blk + 3 <= nblk; blk += 3) {
+          fetch(bs[2], voff, blk + 2);
+          compute(bs[0], blk);
+          fetch(bs[0], voff, blk + 3);
+          compute(bs[1], blk + 1);
+          fetch(bs[1], voff, blk + 4);
+          compute(bs[2], blk + 2);
+        }
+        if (blk < nblk) compute(bs[0], blk);           // nblk mod 3 blocks left: sets 0, 1 hold them
+        if (blk + 1 < nblk) compute(bs[1], blk + 1);
         const bool cok = col < L.n;
         const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
 #pragma unroll
@@ -90,8 +119,8 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
           if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
         }
       }
-      __syncthreads();
     }
+    __syncthreads();     // the next tile's input overwrites XA, which the last layer may still be reading
   }
 }
 
@@ -130,6 +159,7 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   }
   if (xcol0 + k0 > ldx) return DET6D_EINVAL;
   g.k0 = k0; g.width = width;
+  g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
   const size_t lds_bytes = sizeof(float) * 2 * 32 * (size_t)(width + 1);
   if (lds_bytes > 160 * 1024) return DET6D_EINVAL;
@@ -139,7 +169,7 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
     attr_bytes = lds_bytes;
   }
   int blocks = (rows + 31) / 32;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 1024) blocks = 1024;      // (one workgroup per tile, up to 8192, measured no faster: 62 vs 61 us on 4096 tiles)
   hipLaunchKernelGGL(mlp_rows_kernel, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_rows");
 }
