@@ -573,14 +573,16 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   // waves per 32-row tile: 8 for the head's groups (two waves per SIMD from ONE workgroup: the 99 KB of LDS allow only one
   // workgroup per CU), 4 for the SA3 groups (several workgroups per CU); DET6D_GROUP_WAVES (experiments build) overrides
   static const int nw_env = det6d_env_int("DET6D_GROUP_WAVES", 0);
-  // DET6D_GROUP_STREAM: 1 = the streaming form (two workgroups per CU) for the head's wide group; 2 = also for the
-  // [256 -> 256 -> 512] group; 0 (default) = the one-pass form everywhere.  Same bits; measured within +-1 % of each other
-  // in the pipeline (12.98 vs 12.87 k scenes/s, ray-cast scenes 6.06 vs 6.09 k) once the one-pass form fetched its first
-  // weight blocks ahead of the producing phase, so the simpler form stays the default.
-  static const int stream_form = det6d_switch_int("DET6D_GROUP_STREAM", 0);
-  if (stream_form >= 1 && c1 == 256 && c2 == 512 && c3 == 1024)
+  // DET6D_GROUP_STREAM (bit mask): 1 = the streaming form (two workgroups per CU) for the head's wide group
+  // [256 -> 512 -> 1024], 2 = for its narrow group [256 -> 256 -> 512], 3 = both, 0 = the one-pass form everywhere.  Same
+  // bits.  Wide group: within +-1 % of the one-pass form in the pipeline once that form fetched its first weight blocks
+  // ahead of the producing phase (12.98 vs 12.87 k scenes/s, ray-cast scenes 6.06 vs 6.09 k).  Narrow group (default):
+  // its one-pass form holds 143 registers with eight waves, i.e. one workgroup per CU; the streaming form runs it 8-10 %
+  // faster with the chip full (196 -> 180 us, ray-cast scenes 446 -> 400 us) and the pipeline gains 0.5-0.7 %.
+  static const int stream_form = det6d_switch_int("DET6D_GROUP_STREAM", 2);
+  if ((stream_form & 1) && c1 == 256 && c2 == 512 && c3 == 1024)
     return compact ? launch_group_stream<256, 512, 1024, true>(g, s) : launch_group_stream<256, 512, 1024, false>(g, s);
-  if (stream_form >= 2 && c1 == 256 && c2 == 256 && c3 == 512)
+  if ((stream_form & 2) && c1 == 256 && c2 == 256 && c3 == 512)
     return compact ? launch_group_stream<256, 256, 512, true>(g, s) : launch_group_stream<256, 256, 512, false>(g, s);
 #define D6_GROUP(A, B, C, NWD)                                                                        \
   if (c1 == A && c2 == B && c3 == C) {                                                                \

@@ -291,11 +291,11 @@ def test_group_kernel_equals_dense_oracle(oracle_ops, c_in, widths, ns, smin, sp
     np.testing.assert_array_equal(out2.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
+@pytest.mark.parametrize("form", ["0", "3"])
 def test_group_kernel_other_forms(form):
-    """DET6D_GROUP_STREAM: 0 (default) = one-pass form everywhere; 1 = streaming form (second layer in 128-column chunks, two
-    workgroups per CU) for the head's [256 -> 512 -> 1024] group; 2 = for [256 -> 256 -> 512] as well.  Same bits on every
-    route (the switch is read once per process: child process)."""
+    """DET6D_GROUP_STREAM (bit mask): streaming form (second layer in 128-column chunks, two workgroups per CU) for the head's
+    [256 -> 512 -> 1024] group (1) and / or its [256 -> 256 -> 512] group (2); 0 = one-pass form everywhere.  Same bits on
+    every route (the switch is read once per process: child process)."""
     if os.environ.get('DET6D_GROUP_STREAM') is not None:
         pytest.skip('already a child')
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
