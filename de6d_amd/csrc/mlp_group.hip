@@ -291,7 +291,7 @@ __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int t
 }
 
 template <int C1, int C2, int C3, bool COMPACT, int NW>
-__global__ __launch_bounds__(64 * NW) void mlp_group_kernel(const GroupArgs g) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_group_kernel(const GroupArgs g) {
   constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
   constexpr int TN2 = C2 / (32 * NW), TN3 = C3 / (32 * NW);     // accumulator tiles per wave: a wave owns 1 / NW of every layer's columns
   static_assert(TN2 >= 1 && TN3 >= 1, "every wave needs at least one 32-column tile per layer");
