@@ -640,6 +640,7 @@ def main():
     preroll = (args.preroll if args.preroll >= 0 else 8) * capacity   # long enough for clocks / power to settle (~0.2 s)
     preroll += (-(preroll + args.warmup)) % k        # the windows start on group boundaries
     n_windows = args.windows if args.windows > 0 else max(17, -(-768 // k))   # the windows span >= 768 steps of the stream
+    n_windows = max(n_windows, -(-2 * capacity // k))    # ... and never less than two pipeline capacities (deliveries are lumpy)
     tail = capacity
     first = preroll + args.warmup - 1
     last = first + (n_windows - 1) * k + args.steps
@@ -674,6 +675,8 @@ def main():
     windows = sorted(stamps[first + j * k + args.steps] - stamps[first + j * k] for j in range(n_windows))
     window_median = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
     elapsed_own = sum(windows) / len(windows)
+    if elapsed_own <= 0.0:
+        raise SystemExit("bench.py: the windows cover no time (stream too short for the pipeline): raise --windows or --steps")
     elapsed = elapsed_own
 
     # ---- cold: K steps on an EMPTY pipeline, synchronize on both sides (fill + drain inside) ----------------------------
