@@ -190,7 +190,7 @@ def input_producer_rate(cfg, batch, n_raw=120000):
             "frac": round(alg / sec / 8e12, 4)}
 
 
-def pipeline_rate(cfg, model, batch, n, steps=144, n_raw=120000, group=4, n_main=16, prefetch=4):
+def pipeline_rate(cfg, model, batch, n, steps=480, n_raw=120000, group=4, n_main=16, prefetch=4):
     """raw frames -> annotations: det6d_prepare_points (f1) -> captured Det6D passes -> det6d_kitti_annos + one
     D2H + host dictionaries (f2) through the same two-stage pipeline as the headline run; raw frames resident in HBM"""
     from de6d_amd.ops import fused as F
