@@ -293,7 +293,9 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 // timing experiments only (DET6D_FPS_DBG=7): wall clock (100 MHz) at the first and after the last round of every scene
 __device__ unsigned long long d6_fps_clock[2 * 64];
 
-template <int NW, int SLOTS, int G>
+// PSHIFT (timing experiments only, DET6D_FPS_THIN): 2^PSHIFT workgroups per scene, each sampling ITS share of the sorted
+// scene on its own (no exchange: WRONG picks) — the footprint of a sampler spread thinly over several CUs
+template <int NW, int SLOTS, int G, int PSHIFT = 0>
 __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log2s, long long xyz_bstride,
                                                            long long idx_bstride, int idx_add, int dbg,
                                                            const float *__restrict__ xyz,
@@ -305,9 +307,10 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   __shared__ unsigned short korig[64 * NW * SLOTS];   // sorted position -> original index (n <= 65536)
   const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
   if (D6_DBG_IS(9)) d6_sampler_priority();   // raised wave priority measured 1 % SLOWER in the pipeline (9668 vs 9750 scenes/s): DET6D_FPS_DBG=9 turns it on
-  xyz += (size_t)blockIdx.x * xyz_bstride;
-  perm += (size_t)blockIdx.x * n;
-  idxs += (size_t)blockIdx.x * idx_bstride;
+  const int scene = blockIdx.x >> PSHIFT, part = blockIdx.x & ((1 << PSHIFT) - 1);
+  xyz += (size_t)scene * xyz_bstride;
+  perm += (size_t)scene * n + (size_t)part * (64 * NW * SLOTS);
+  idxs += (size_t)scene * idx_bstride;
 
   float px[SLOTS], py[SLOTS], pz[SLOTS], pt[SLOTS];
   float lox[G], loy[G], loz[G], hix[G], hiy[G], hiz[G];
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   __syncthreads();
 
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
-  if (h == 0) idxs[0] = idx_add;
+  if (h == 0 && part == 0) idxs[0] = idx_add;
   if (D6_DBG_IS(7) && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x] = wall_clock64();
   // cached arg-max of every group of this wave (uniform)
   float cg_val[G], cg_x[G], cg_y[G], cg_z[G];
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
     cx = d6_readlane_f(x2, ww);
     cy = d6_readlane_f(y2, ww);
     cz = d6_readlane_f(z2, ww);
-    if (h == 0) idxs[r] = old + idx_add;
+    if (h == 0 && (r & ((1 << PSHIFT) - 1)) == part) idxs[r] = old + idx_add;   // (PSHIFT > 0: part p supplies every 2^PSHIFT-th pick)
   }
   if (D6_DBG_IS(7) && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
@@ -445,6 +448,15 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
     // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two
     // boxes (8-slot groups) per wave (1.08: the second box test and reduction cost more than the shorter scans
     // save); 8 = 8 waves x 32 slots (1.15); 84 = 8 x 32 in four 8-slot groups (1.36)
+#ifdef DET6D_EXPERIMENTS
+    static const int thin = det6d_env_int("DET6D_FPS_THIN", 0);   // timing only, WRONG picks: 4 workgroups of 4 waves per scene
+    if (thin) {
+      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+      hipLaunchKernelGGL((fps_skip_kernel<4, 16, 1, 2>), dim3(4 * b), dim3(256), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, dbg, xyz, perm, idx);
+      return det6d_check_launch("det6d_fps (thin what-if)");
+    }
+#endif
     if (skip == 8) {
       hipLaunchKernelGGL(skip_group_order_kernel<32>, dim3(1, b), dim3(512), 0, stream, n, log2s, perm);
       hipLaunchKernelGGL((fps_skip_kernel<8, 32, 1>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
