@@ -780,8 +780,12 @@ DET6D_API int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *
     }
     return det6d_check_launch("det6d_mlp_chain3_compact");
   }
+  // grid: up to 2048 workgroups, each wave walks ceil(live tiles / waves) tiles (measured on 32-scene passes, SA1's wide
+  // group alone / with the chip full: 768 workgroups 137 / 65 us, 1024: 115 / 64, 2048: 97 / 65, 4096: 87 / 70; ray-cast
+  // scenes 578 / 205, 507 / 205, 366 / 201, 299 / 206)
   int blocks = det6d_divup(ntiles, 4);
-  if (blocks > 1024) blocks = 1024;
+  const int cap = 2048;
+  if (blocks > cap) blocks = cap;
   if (c1 == 16)
     hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32, 32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
   else
