@@ -181,7 +181,8 @@ struct GroupLayer {
 // produces columns 4q + 4 EPR i of its row:
 // X1[row][c] = relu(fma(dz, W1[2][c], fma(dy, W1[1][c], fma(dx, W1[0][c], P[p][c]))) + s1[c]) ----
 template <int C1, bool COMPACT, int EPR>
-__device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile, const int tid, float *__restrict__ X1) {
+__device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile, const int tid, float *__restrict__ X1,
+                                             int *__restrict__ tagbuf) {
   constexpr int LD1 = C1 + 1;
   const int erow = tid / EPR, eq = tid % EPR;
     {
@@ -191,6 +192,7 @@ __device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile,
       bool real = true;
       if (COMPACT) {
         const int tag = g.crow_c[r];
+        if (eq == 0) tagbuf[erow] = tag;     // the pooling epilogue takes the rows' tags from LDS (visible after the barrier)
         real = tag >= 0;
         cj = tag & 0x1fffffff;
         prow = g.crow_p[r];
@@ -227,14 +229,14 @@ __device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile,
 template <int TN3, bool COMPACT>
 __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int tile, f32x16 (&acc)[TN3], const float (&sh3)[TN3],
                                                  const int colbase, const int l31, const int kh, const int h1, const int h2,
-                                                 const int h3, const int h4, const int h5) {
+                                                 const int h3, const int h4, const int h5, const int *__restrict__ tagbuf) {
     if (COMPACT) {
       const int sc = g_class(tile * 32, h1, h2, h3, h4, h5);
       if (sc < 4) {       // classes 1, 2: every accumulator (pair) is a centre part of its own
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           if (sc == 2 && (e & 1)) continue;
-          const int tag = g.crow_c[tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+          const int tag = tagbuf[(e & 3) + 8 * (e >> 2) + 4 * kh];
           if (tag < 0) continue;
           float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + colbase;
 #pragma unroll
@@ -248,7 +250,7 @@ __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int t
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const int rr = g_out_row(sc, qq, kh);
-          oc[qq] = rr >= 0 ? g.crow_c[tile * 32 + rr] : -1;
+          oc[qq] = rr >= 0 ? tagbuf[rr] : -1;
         }
 #pragma unroll
         for (int j = 0; j < TN3; ++j) {
@@ -298,6 +300,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
   extern __shared__ float lds[];
   float *X1 = lds;
   float *X2 = lds + 32 * LD1;
+  int *tags = reinterpret_cast<int *>(lds + 32 * (LD1 + LD2));    // 2 x 32 row tags, by tile parity (no barrier between a tile's
+  int it = 0;                                                     // epilogue and the next tile's first layer)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   if ((int)blockIdx.x >= live_tiles) return;
@@ -322,7 +326,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
     GroupLayer<C1, TN2, LD1> second;
     GroupLayer<C2, TN3, LD2> third;
     second.start(srd2, voff2, g.ldw2 * 4);
-    group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1);
+    int *tagbuf = tags + 32 * (it++ & 1);
+    group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1, tagbuf);
     __syncthreads();
     D6_PHASE(0);
     // ---- layer 2: X2 = relu(X1 W2 + s2) ----
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
     third.run(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
     D6_WAVE_T1(ph_w3);
     D6_PHASE(3);
-    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / NW), l31, kh, h1, h2, h3, h4, h5);
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / NW), l31, kh, h1, h2, h3, h4, h5, tagbuf);
     // no barrier here: the next tile's layer 1 writes X1, which every wave finished reading before the barrier above;
     // X2 is rewritten only after the next tile's first barrier, which no wave passes before it has left layer 3
     D6_PHASE(4);
@@ -432,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
   float *X1 = lds;
   float *Y0 = lds + 32 * LD1;
   float *Y1 = Y0 + 32 * LDY;
+  int *tags = reinterpret_cast<int *>(Y1 + 32 * LDY);             // 2 x 32 row tags, by tile parity
+  int it = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   if ((int)blockIdx.x >= live_tiles) return;
@@ -459,7 +466,8 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
   };
 
   for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
-    group_layer1<C1, COMPACT, 8>(g, tile, tid, X1);
+    int *tagbuf = tags + 32 * (it++ & 1);
+    group_layer1<C1, COMPACT, 8>(g, tile, tid, X1, tagbuf);
     __syncthreads();
     f32x16 acc[TN3];
 #pragma unroll
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
         __syncthreads();
       }
     }
-    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5);
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5, tagbuf);
     // no barrier here: X1 is rewritten by the next tile's layer 1, every wave is past its last second-layer chunk (the
     // barrier above); Y0 is rewritten after the next tile's first barrier, Y1 two barriers later
   }
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
 
 template <int C1, int C2, int C3, bool COMPACT>
 int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
-  const size_t lds_bytes = sizeof(float) * 32 * (size_t)(C1 + 1 + 2 * 129);
+  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void *)mlp_group_stream_kernel<C1, C2, C3, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -501,7 +509,7 @@ int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
 
 template <int C1, int C2, int C3, bool COMPACT, int NW>
 int launch_group(const GroupArgs &g, hipStream_t stream) {
-  const size_t lds_bytes = sizeof(float) * 32 * (size_t)(C1 + 1 + C2 + 1);
+  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + C2 + 1) + 64);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void *)mlp_group_kernel<C1, C2, C3, COMPACT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
