@@ -37,6 +37,7 @@ struct GroupArgs {
   const int *idx; int n, m, ns; const int *cnt;   // dense rows
   const int *hdr; const int *crow_p; const int *crow_c;   // compact rows
   float *y; int ldy; int col0;
+  int pre;                                        // A/B switch: list entries of the next tile requested a K loop ahead
 };
 
 // ---- compact-row helpers (same conventions as mlp_chain.hip / linear.hip; see compact.hip for the list layout) ----
@@ -180,9 +181,18 @@ struct GroupLayer {
 // ---- layer 1 of a 32-row tile (expand.hip's arithmetic): EPR threads per row, thread (row = tid / EPR, q = tid % EPR)
 // produces columns 4q + 4 EPR i of its row:
 // X1[row][c] = relu(fma(dz, W1[2][c], fma(dy, W1[1][c], fma(dx, W1[0][c], P[p][c]))) + s1[c]) ----
+// The row's list entry (compact: tag + point row; dense: neighbour index) is the first of two dependent global loads of the
+// gather; group_row_entry() requests it for the NEXT tile before the current tile's third layer (ahead by a whole K loop).
+template <bool COMPACT, int EPR>
+__device__ __forceinline__ void group_row_entry(const GroupArgs &g, const int tile, const int tid, int &e0, int &e1) {
+  const int r = tile * 32 + tid / EPR;
+  if (COMPACT) { e0 = g.crow_c[r]; e1 = g.crow_p[r]; }
+  else { e0 = g.idx[r]; e1 = 0; }
+}
+
 template <int C1, bool COMPACT, int EPR>
 __device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile, const int tid, float *__restrict__ X1,
-                                             int *__restrict__ tagbuf) {
+                                             int *__restrict__ tagbuf, const int e0, const int e1) {
   constexpr int LD1 = C1 + 1;
   const int erow = tid / EPR, eq = tid % EPR;
     {
@@ -191,14 +201,14 @@ __device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile,
       int cj;
       bool real = true;
       if (COMPACT) {
-        const int tag = g.crow_c[r];
+        const int tag = e0;
         if (eq == 0) tagbuf[erow] = tag;     // the pooling epilogue takes the rows' tags from LDS (visible after the barrier)
         real = tag >= 0;
         cj = tag & 0x1fffffff;
-        prow = g.crow_p[r];
+        prow = e1;
       } else {
         cj = r / g.ns;
-        prow = (long long)(cj / g.m) * g.n + g.idx[r];
+        prow = (long long)(cj / g.m) * g.n + e0;
       }
       float dx = 0.f, dy = 0.f, dz = 0.f;
       if (real) {
@@ -319,6 +329,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
   for (int j = 0; j < TN3; ++j) sh3[j] = g.s3[wave * (C3 / NW) + tile_col<TN3>(j, l31)];
 
   D6_PHASE_DECL
+  int e0, e1;
+  group_row_entry<COMPACT, 2 * NW>(g, blockIdx.x, tid, e0, e1);
   for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
 #ifdef DET6D_EXPERIMENTS
     ++ph_tiles;
@@ -327,7 +339,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
     GroupLayer<C2, TN3, LD2> third;
     second.start(srd2, voff2, g.ldw2 * 4);
     int *tagbuf = tags + 32 * (it++ & 1);
-    group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1, tagbuf);
+    if (!g.pre) group_row_entry<COMPACT, 2 * NW>(g, tile, tid, e0, e1);
+    group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1, tagbuf, e0, e1);
     __syncthreads();
     D6_PHASE(0);
     // ---- layer 2: X2 = relu(X1 W2 + s2) ----
@@ -358,6 +371,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     D6_WAVE_T0;
+    if (g.pre) {          // the next tile's list entries, a K loop ahead of its first layer (the last tile re-reads its own)
+      const int nt = tile + (int)gridDim.x;
+      group_row_entry<COMPACT, 2 * NW>(g, nt < live_tiles ? nt : tile, tid, e0, e1);
+    }
     third.run(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
     D6_WAVE_T1(ph_w3);
     D6_PHASE(3);
@@ -467,7 +484,9 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
 
   for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
     int *tagbuf = tags + 32 * (it++ & 1);
-    group_layer1<C1, COMPACT, 8>(g, tile, tid, X1, tagbuf);
+    int e0, e1;
+    group_row_entry<COMPACT, 8>(g, tile, tid, e0, e1);
+    group_layer1<C1, COMPACT, 8>(g, tile, tid, X1, tagbuf, e0, e1);
     __syncthreads();
     f32x16 acc[TN3];
 #pragma unroll
@@ -577,6 +596,8 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   g.idx = idx; g.n = n; g.m = m; g.ns = ns; g.cnt = cnt;
   g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
   g.y = y; g.ldy = ldy; g.col0 = col0;
+  static const int pre_entries = det6d_switch_int("DET6D_GROUP_PRE", 1);
+  g.pre = pre_entries;
   hipStream_t s = (hipStream_t)stream;
   // waves per 32-row tile: 8 for the head's groups (two waves per SIMD from ONE workgroup: the 99 KB of LDS allow only one
   // workgroup per CU), 4 for the SA3 groups (several workgroups per CU); DET6D_GROUP_WAVES (experiments build) overrides

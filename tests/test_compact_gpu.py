@@ -291,16 +291,17 @@ def test_group_kernel_equals_dense_oracle(oracle_ops, c_in, widths, ns, smin, sp
     np.testing.assert_array_equal(out2.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("form", ["0", "3"])
-def test_group_kernel_other_forms(form):
-    """DET6D_GROUP_STREAM (bit mask): streaming form (second layer in 128-column chunks, two workgroups per CU) for the head's
-    [256 -> 512 -> 1024] group (1) and / or its [256 -> 256 -> 512] group (2); 0 = one-pass form everywhere.  Same bits on
-    every route (the switch is read once per process: child process)."""
-    if os.environ.get('DET6D_GROUP_STREAM') is not None:
+@pytest.mark.parametrize("env", [{'DET6D_GROUP_STREAM': '0'}, {'DET6D_GROUP_STREAM': '3'}, {'DET6D_GROUP_PRE': '0'}])
+def test_group_kernel_other_forms(env):
+    """DET6D_GROUP_STREAM (bit mask, default 2): streaming form (second layer in 128-column chunks, two workgroups per CU) for
+    the head's [256 -> 512 -> 1024] group (1) and / or its [256 -> 256 -> 512] group (2); 0 = one-pass form everywhere.
+    DET6D_GROUP_PRE=0: the rows' list entries loaded inside the first layer instead of a K loop ahead.  Same bits on every
+    route (the switches are read once per process: child process)."""
+    if any(k in os.environ for k in env):
         pytest.skip('already a child')
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
                           'test_group_kernel_equals_dense_oracle or test_group_kernel_on_degenerate_lists'],
-                         env=dict(os.environ, DET6D_GROUP_STREAM=form), cwd=ROOT, capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout
 
