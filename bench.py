@@ -408,6 +408,12 @@ def compact_fill(model, points, batch):
     return out
 
 
+def coalesce_factor(batch, steps, scenes_per_pass=32):
+    """batches per pass: the largest d with d * batch <= scenes_per_pass that divides `steps` (a window of K steps is then a
+    whole number of passes: exactly K steps are delivered inside it)"""
+    return max(d for d in range(1, max(1, scenes_per_pass // max(1, batch)) + 1) if steps % d == 0)
+
+
 def selfcheck(model, pipe, b):
     """every pass's LAST finalised result against an eager pass over the same batch, bit for bit (the captured segments,
     the grouped first sampler and the stream choreography must not change a single detection)"""
@@ -526,7 +532,7 @@ def main():
     if args.merge < 0:
         # the largest number of batches per pass that keeps a pass <= 32 scenes and divides K (a window of K steps is then a
         # whole number of passes: exactly K steps are delivered inside it)
-        args.merge = 1 if (args.no_graph or args.group == 0) else max(d for d in range(1, max(1, 32 // max(1, args.batch)) + 1) if args.steps % d == 0)
+        args.merge = 1 if (args.no_graph or args.group == 0) else coalesce_factor(args.batch, args.steps)
     if args.group < 0:
         args.group = 4 if args.merge == 1 else 1
     if args.streams < 0:

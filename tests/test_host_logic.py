@@ -212,3 +212,12 @@ def test_scene_pipeline_step_accounting_with_coalesced_passes():
     assert len(merged) == 3 and all(m.shape == (12, 5) for m in merged)
     assert merged[2][:6].eq(4).all() and merged[2][6:].eq(0).all()      # cyclic
     assert ScenePipeline.coalesce(batches, 1)[3] is batches[3]
+
+
+def test_bench_coalesce_factor():
+    """bench.py: batches per pass = largest divisor of K that keeps a pass <= 32 scenes"""
+    import bench
+    assert bench.coalesce_factor(8, 20) == 4 and bench.coalesce_factor(8, 192) == 4
+    assert bench.coalesce_factor(8, 7) == 1 and bench.coalesce_factor(8, 6) == 3
+    assert bench.coalesce_factor(4, 20) == 5 and bench.coalesce_factor(4, 192) == 8
+    assert bench.coalesce_factor(32, 20) == 1 and bench.coalesce_factor(64, 20) == 1
