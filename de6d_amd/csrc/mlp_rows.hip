@@ -19,7 +19,7 @@ constexpr int kMaxLayers = 4;
 struct RowsArgs {
   int rows;
   const float *x; int ldx; int xcol0; int k0;     // input: columns [xcol0, xcol0 + k0) of x (rows, ldx)
-  int width;                                      // LDS row width (max of k0 and the hidden widths)
+  int wa, wb;                                     // LDS row widths: XA holds the input and the outputs of odd layers, XB the outputs of even layers
   int vec4;                                       // input rows are 16-byte aligned and k0 % 4 == 0
   int nlayers[2];
   det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
@@ -27,8 +27,8 @@ struct RowsArgs {
 
 __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   extern __shared__ float lds[];
-  const int LD = g.width + 1;
-  float *XA = lds, *XB = lds + 32 * LD;
+  const int LDA = g.wa + 1, LDB = g.wb + 1;       // odd strides: conflict-free A fragments
+  float *XA = lds, *XB = lds + 32 * LDA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int chain = blockIdx.y;
   const int nl = g.nlayers[chain];
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
     {
       const int r = tile * 32 + lrow;
       const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0;
-      float *dst = XA + lrow * LD;
+      float *dst = XA + lrow * LDA;
       if (g.vec4) {
         for (int c = 4 * lq; c < g.k0; c += 32) {
           const f32x4r v = *reinterpret_cast<const f32x4r *>(src + c);
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
       const det6d_rows_layer &L = g.layers[chain][l];
       const float *X = (l & 1) ? XB : XA;
       float *Y = (l & 1) ? XA : XB;
+      const int LD = (l & 1) ? LDB : LDA, LDY = (l & 1) ? LDA : LDB;
       const bool last = l == nl - 1;
       const __amdgpu_buffer_rsrc_t srd =
           __builtin_amdgcn_make_buffer_rsrc((void *)(L.w + (size_t)L.wrow0 * L.ldw), 0, (unsigned)((size_t)L.k * L.ldw * 4), 0x00020000);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
           const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
           float v = acc[e] + sh;
           if (L.act == 1) v = d6_relu(v);
-          if (!last && cok) Y[row * LD + col] = v;
+          if (!last && cok) Y[row * LDY + col] = v;
           const int r = tile * 32 + row;
           if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
         }
@@ -131,7 +132,7 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   if (rows < 0 || !x || ldx <= 0 || xcol0 < 0 || nchains < 1 || nchains > 2 || !nlayers || !layers) return DET6D_EINVAL;
   RowsArgs g;
   g.rows = rows; g.x = x; g.ldx = ldx; g.xcol0 = xcol0;
-  int width = 0, k0 = -1, off = 0;
+  int wa = 0, wb = 0, k0 = -1, off = 0;
   for (int c = 0; c < 2; ++c) g.nlayers[c] = 0;
   for (int c = 0; c < nchains; ++c) {
     const int nl = nlayers[c];
@@ -151,17 +152,17 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
       if (l == nl - 1 && !L.out) return DET6D_EINVAL;
       if (L.out && (L.ldo < L.ocol0 + L.n)) return DET6D_EINVAL;
       if ((size_t)L.k * L.ldw * 4 >= 0xfff00000ull) return DET6D_EINVAL;
-      if (L.k > width) width = L.k;
+      if (l & 1) { if (L.k > wb) wb = L.k; } else { if (L.k > wa) wa = L.k; }     // layer l reads XA (even l) / XB (odd l)
       kin = L.n;
       g.layers[c][l] = L;
     }
     off += nl;
   }
   if (xcol0 + k0 > ldx) return DET6D_EINVAL;
-  g.k0 = k0; g.width = width;
+  g.k0 = k0; g.wa = wa; g.wb = wb > 0 ? wb : 1;
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
-  const size_t lds_bytes = sizeof(float) * 2 * 32 * (size_t)(width + 1);
+  const size_t lds_bytes = sizeof(float) * 32 * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1));
   if (lds_bytes > 160 * 1024) return DET6D_EINVAL;
   static size_t attr_bytes = 0;
   if (lds_bytes > attr_bytes) {
