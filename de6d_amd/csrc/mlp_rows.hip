@@ -21,10 +21,12 @@ struct RowsArgs {
   const float *x; int ldx; int xcol0; int k0;     // input: columns [xcol0, xcol0 + k0) of x (rows, ldx)
   int wa, wb;                                     // LDS row widths: XA holds the input and the outputs of odd layers, XB the outputs of even layers
   int vec4;                                       // input rows are 16-byte aligned and k0 % 4 == 0
+  int kchunk;                                     // columns of the input held in LDS at a time (== k0: all of them)
   int nlayers[2];
   det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
 };
 
+template <bool CHUNKED>
 __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   extern __shared__ float lds[];
   const int LDA = g.wa + 1, LDB = g.wb + 1;       // odd strides: conflict-free A fragments
@@ -35,21 +37,24 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   const int ntiles_rows = (g.rows + 31) >> 5;
   const int lrow = tid >> 3, lq = tid & 7;
   for (int tile = blockIdx.x; tile < ntiles_rows; tile += gridDim.x) {
-    // ---- input tile -> XA (rows past the end: zeros); 8 threads per row, 16 bytes each where the rows allow it ----
-    {
+    // ---- input tile (columns [c0, c0 + kchunk)) -> XA (rows past the end: zeros); 8 threads per row, 16 bytes each where
+    // the rows allow it ----
+    auto load_input = [&](const int c0) {
+      const int kw = CHUNKED ? g.kchunk : g.k0;
       const int r = tile * 32 + lrow;
-      const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0;
+      const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0 + c0;
       float *dst = XA + lrow * LDA;
       if (g.vec4) {
-        for (int c = 4 * lq; c < g.k0; c += 32) {
+        for (int c = 4 * lq; c < kw; c += 32) {
           const f32x4r v = *reinterpret_cast<const f32x4r *>(src + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dst[c + e] = r < g.rows ? v[e] : 0.f;
         }
       } else {
-        for (int c = lq; c < g.k0; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
+        for (int c = lq; c < kw; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
       }
-    }
+    };
+    load_input(0);
     for (int l = 0; l < nl; ++l) {
       const det6d_rows_layer &L = g.layers[chain][l];
       const float *X = (l & 1) ? XB : XA;
@@ -72,6 +77,66 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
         for (int u = 0; u < 16; ++u)
           b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, 2 * (bb * 16 + u) * ldw_bytes, 0));
       };
+      if (CHUNKED && l == 0) {
+        // ---- wide input (the head's towers: 512 columns), at most four column tiles: the input passes through LDS in
+        // chunks of kchunk columns = K-chunks of this layer in ascending order, every wave keeps the accumulator of ITS
+        // column tile across the chunks (the same ascending-k chain); 49 instead of 82 KB of LDS: three workgroups per CU
+        const int cblk = g.kchunk >> 5;
+        const bool mine = wave < ncol_tiles;
+        const int col = 32 * wave + l31;
+        const uint32_t voff = (uint32_t)(kh * L.ldw + col) * 4u;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int b0 = 0; b0 < nblk; b0 += cblk) {
+          if (b0 > 0) {
+            __syncthreads();                    // every wave is done with the previous chunk
+            load_input(32 * b0);
+          }
+          if (mine) {
+            fetch(bs[0], voff, b0);
+            fetch(bs[1], voff, b0 + 1);
+          }
+          __syncthreads();
+          if (mine) {
+            auto compute = [&](const float (&b)[16], int blk) {
+              const float *xa = X + l31 * LD + 32 * (blk - b0) + kh;
+              float a[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) a[u] = xa[2 * u];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            };
+            const int bend = b0 + cblk;
+            int blk = b0;
+#pragma unroll 1
+            for (; blk + 3 <= bend; blk += 3) {
+              fetch(bs[2], voff, blk + 2);
+              compute(bs[0], blk);
+              fetch(bs[0], voff, blk + 3);
+              compute(bs[1], blk + 1);
+              fetch(bs[1], voff, blk + 4);
+              compute(bs[2], blk + 2);
+            }
+            if (blk < bend) compute(bs[0], blk);
+            if (blk + 1 < bend) compute(bs[1], blk + 1);
+          }
+        }
+        if (mine) {
+          const bool cok = col < L.n;
+          const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+            float v = acc[e] + sh;
+            if (L.act == 1) v = d6_relu(v);
+            if (!last && cok) Y[row * LDY + col] = v;
+            const int r = tile * 32 + row;
+            if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
+          }
+        }
+        continue;
+      }
       if (wave < ncol_tiles) {
         const uint32_t voff0 = (uint32_t)(kh * L.ldw + 32 * wave + l31) * 4u;
         fetch(bs[0], voff0, 0);
@@ -160,17 +225,32 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   }
   if (xcol0 + k0 > ldx) return DET6D_EINVAL;
   g.k0 = k0; g.wa = wa; g.wb = wb > 0 ? wb : 1;
+  g.kchunk = k0;
+  if (k0 >= 512 && (k0 % 256) == 0) {      // a wide input whose first layers have at most four column tiles: K-chunks of 256
+    bool narrow = true;
+    int wa_rest = 256, o = 0;
+    for (int c = 0; c < nchains; ++c) {
+      if (layers[o].n > 128) narrow = false;
+      for (int l = 2; l < nlayers[c]; l += 2) if (layers[o + l].k > wa_rest) wa_rest = layers[o + l].k;
+      o += nlayers[c];
+    }
+    if (narrow) { g.kchunk = 256; g.wa = wa_rest; }
+  }
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
   const size_t lds_bytes = sizeof(float) * 32 * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1));
   if (lds_bytes > 160 * 1024) return DET6D_EINVAL;
   static size_t attr_bytes = 0;
   if (lds_bytes > attr_bytes) {
-    hipFuncSetAttribute((const void *)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_bytes = lds_bytes;
   }
   int blocks = (rows + 31) / 32;
   if (blocks > 1024) blocks = 1024;      // (one workgroup per tile, up to 8192, measured no faster: 62 vs 61 us on 4096 tiles)
-  hipLaunchKernelGGL(mlp_rows_kernel, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+  if (g.kchunk < g.k0)
+    hipLaunchKernelGGL(mlp_rows_kernel<true>, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(mlp_rows_kernel<false>, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_rows");
 }
