@@ -26,32 +26,38 @@ struct RowsArgs {
   det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
 };
 
-template <bool CHUNKED>
+// RB = 32-row blocks per tile.  RB = 2 (narrow stacks: at most two column tiles per layer, e.g. [96 -> 64 -> 32 -> 1]): the
+// work items of a layer are (row block, column tile) pairs, so that a layer of two column tiles keeps all four waves busy
+// and a layer of one keeps two, instead of two and one.
+template <bool CHUNKED, int RB>
 __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
+  static_assert(!(CHUNKED && RB != 1), "the K-chunked first layer keeps one accumulator per wave");
+  constexpr int TR = 32 * RB;                     // rows per tile
   extern __shared__ float lds[];
   const int LDA = g.wa + 1, LDB = g.wb + 1;       // odd strides: conflict-free A fragments
-  float *XA = lds, *XB = lds + 32 * LDA;
+  float *XA = lds, *XB = lds + TR * LDA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int chain = blockIdx.y;
   const int nl = g.nlayers[chain];
-  const int ntiles_rows = (g.rows + 31) >> 5;
-  const int lrow = tid >> 3, lq = tid & 7;
+  const int ntiles_rows = (g.rows + TR - 1) / TR;
+  constexpr int TPR = 8 / RB;                     // threads per row of the input tile
+  const int lrow = tid / TPR, lq = tid % TPR;
   for (int tile = blockIdx.x; tile < ntiles_rows; tile += gridDim.x) {
     // ---- input tile (columns [c0, c0 + kchunk)) -> XA (rows past the end: zeros); 8 threads per row, 16 bytes each where
     // the rows allow it ----
     auto load_input = [&](const int c0) {
       const int kw = CHUNKED ? g.kchunk : g.k0;
-      const int r = tile * 32 + lrow;
+      const int r = tile * TR + lrow;
       const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0 + c0;
       float *dst = XA + lrow * LDA;
       if (g.vec4) {
-        for (int c = 4 * lq; c < kw; c += 32) {
+        for (int c = 4 * lq; c < kw; c += 4 * TPR) {
           const f32x4r v = *reinterpret_cast<const f32x4r *>(src + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dst[c + e] = r < g.rows ? v[e] : 0.f;
         }
       } else {
-        for (int c = lq; c < kw; c += 8) dst[c] = r < g.rows ? src[c] : 0.f;
+        for (int c = lq; c < kw; c += TPR) dst[c] = r < g.rows ? src[c] : 0.f;
       }
     };
     load_input(0);
@@ -137,27 +143,30 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
         }
         continue;
       }
-      if (wave < ncol_tiles) {
-        const uint32_t voff0 = (uint32_t)(kh * L.ldw + 32 * wave + l31) * 4u;
+      // work items: (row block rb, column tile j), item = RB * j + rb; wave w takes items w, w + 4, ...
+      const int nitems = RB * ncol_tiles;
+      if (wave < nitems) {
+        const uint32_t voff0 = (uint32_t)(kh * L.ldw + 32 * (wave / RB) + l31) * 4u;
         fetch(bs[0], voff0, 0);
         fetch(bs[1], voff0, 1);
       }
       __syncthreads();
-      for (int j = wave; j < ncol_tiles; j += 4) {
+      for (int item = wave; item < nitems; item += 4) {
+        const int j = item / RB, rb = item % RB;
         const int col = 32 * j + l31;
         const uint32_t voff = (uint32_t)(kh * L.ldw + col) * 4u;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         auto compute = [&](const float (&b)[16], int blk) {
-          const float *xa = X + l31 * LD + 32 * blk + kh;
+          const float *xa = X + (32 * rb + l31) * LD + 32 * blk + kh;
           float a[16];
 #pragma unroll
           for (int u = 0; u < 16; ++u) a[u] = xa[2 * u];
 #pragma unroll
           for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
         };
-        if (j != wave) {
+        if (item != wave) {
           fetch(bs[0], voff, 0);
           fetch(bs[1], voff, 1);
         }
@@ -177,11 +186,11 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
         const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+          const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
           float v = acc[e] + sh;
           if (L.act == 1) v = d6_relu(v);
           if (!last && cok) Y[row * LDY + col] = v;
-          const int r = tile * 32 + row;
+          const int r = tile * TR + row;
           if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
         }
       }
@@ -238,19 +247,29 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   }
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
-  const size_t lds_bytes = sizeof(float) * 32 * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1));
+  // narrow stacks (every layer at most two column tiles, single chain, many rows): 64-row tiles
+  int max_tiles = 0;
+  for (int c = 0, o = 0; c < nchains; o += nlayers[c], ++c)
+    for (int l = 0; l < nlayers[c]; ++l) max_tiles = max_tiles > (layers[o + l].n + 31) / 32 ? max_tiles : (layers[o + l].n + 31) / 32;
+  // DET6D_ROWS_RB: 2 (default) = 64-row tiles for narrow stacks over >= 16384 rows, 3 = over any number of rows, 1 = never
+  static const int rb_env = det6d_switch_int("DET6D_ROWS_RB", 2);
+  const int rb = (rb_env >= 2 && g.kchunk == g.k0 && max_tiles <= 2 && (rows >= 16384 || rb_env == 3)) ? 2 : 1;
+  const size_t lds_bytes = sizeof(float) * 32 * rb * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1));
   if (lds_bytes > 160 * 1024) return DET6D_EINVAL;
   static size_t attr_bytes = 0;
   if (lds_bytes > attr_bytes) {
-    hipFuncSetAttribute((const void *)mlp_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipFuncSetAttribute((const void *)mlp_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_rows_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_rows_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void *)mlp_rows_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_bytes = lds_bytes;
   }
-  int blocks = (rows + 31) / 32;
+  int blocks = (rows + 32 * rb - 1) / (32 * rb);
   if (blocks > 1024) blocks = 1024;      // (one workgroup per tile, up to 8192, measured no faster: 62 vs 61 us on 4096 tiles)
   if (g.kchunk < g.k0)
-    hipLaunchKernelGGL(mlp_rows_kernel<true>, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((mlp_rows_kernel<true, 1>), dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+  else if (rb == 2)
+    hipLaunchKernelGGL((mlp_rows_kernel<false, 2>), dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL(mlp_rows_kernel<false>, dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((mlp_rows_kernel<false, 1>), dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
   return det6d_check_launch("det6d_mlp_rows");
 }

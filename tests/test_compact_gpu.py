@@ -291,6 +291,19 @@ def test_group_kernel_equals_dense_oracle(oracle_ops, c_in, widths, ns, smin, sp
     np.testing.assert_array_equal(out2.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("rb", ["1", "3"])
+def test_plain_layer_stacks_other_tiles(rb):
+    """DET6D_ROWS_RB: 64-row tiles for the narrow stacks (3 = whatever the row count, so that the small test shapes take
+    them; 1 = never).  Same bits (child process: the switch is read once)."""
+    if os.environ.get('DET6D_ROWS_RB') is not None:
+        pytest.skip('already a child')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                          'test_plain_layer_stacks_equal_the_layer_by_layer_oracle'],
+                         env=dict(os.environ, DET6D_ROWS_RB=rb), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'passed' in out.stdout
+
+
 @pytest.mark.parametrize("env", [{'DET6D_GROUP_STREAM': '0'}, {'DET6D_GROUP_STREAM': '3'}, {'DET6D_GROUP_PRE': '0'}])
 def test_group_kernel_other_forms(env):
     """DET6D_GROUP_STREAM (bit mask, default 2): streaming form (second layer in 128-column chunks, two workgroups per CU) for
