@@ -259,6 +259,76 @@ def gen_model():
     print("det6d_car_state_dict.json", len(keys), "entries")
 
 
+# ----------------------------------------------------------------------------- whole model, FULL width
+FULL_CASES = (  # name, scene generator, scene seed, tilt
+    ('uniform', 'make_batch', 4100, False),
+    ('beam', 'beam_batch', 4200, True),
+)
+
+
+def gen_model_full():
+    """det6d_car.yaml (the benchmarked widths: K up to 1536, twelve stacked layers between the input and the boxes) through
+    the REFERENCE's own Python model (pointnet2_backbone.py:199-263, point_head_box6d_vote.py:794-903,
+    detector3d_template.py:178-284; torch-CPU Conv/BN/ReLU), one 16384-point scene per case, the oracle's ops behind the
+    extension-module names as in gen_model().  Stores what pins the north star at this width: the sampled point sets of
+    all three levels, the confidence scores that drive S-FPS, the candidate / vote points, box codes, decoded boxes, class
+    logits and the kept detections.  Inputs and weights are regenerated from seeds by the tests (nothing of the reference
+    travels)."""
+    import yaml
+    EasyDict = install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import pcdet.models as ref_models
+    assert ref_models.__file__.startswith(REF)
+    from tests import util as tutil
+    from de6d_amd.runtime import load_config, build_model
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "de6d_amd/cfgs/kitti_models/det6d_car.yaml")))
+    weight_seed = 31
+    ours = build_model(load_config('kitti_models/det6d_car.yaml'), seed=weight_seed)
+    sd = ours.state_dict()
+
+    class DS(object):
+        class_names = cfg['CLASS_NAMES']
+        point_feature_encoder = EasyDict(num_point_features=4)
+        grid_size = None
+        voxel_size = None
+        point_cloud_range = np.array(cfg['DATA_CONFIG']['POINT_CLOUD_RANGE'], np.float32)
+        depth_downsample_factor = None
+
+    ref = ref_models.build_network(EasyDict(cfg['MODEL']), num_class=1, dataset=DS())
+    assert list(ref.state_dict().keys()) == list(sd.keys())
+    ref.load_state_dict(sd)
+    ref.eval()
+    out = dict(weight_seed=np.int64(weight_seed), n=np.int64(16384), cases=np.array([c[0] for c in FULL_CASES]))
+    for name, gen, seed, tilt in FULL_CASES:
+        b, n = 1, 16384
+        batch = getattr(tutil, gen)(seed, b, n, tilt=tilt)
+        pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
+        bd = {'batch_size': b, 'points': torch.from_numpy(pts)}
+        with torch.no_grad():
+            pred, _ = ref(bd)
+        out[name + '_scene_seed'] = np.int64(seed)
+        out[name + '_tilt'] = np.int64(tilt)
+        out[name + '_generator'] = np.array(gen)
+        for i, t in enumerate(bd['point_coords_list']):
+            out['%s_point_coords_list_%d' % (name, i)] = t.numpy()[:, 1:]
+        for i, t in enumerate(bd['point_scores_list']):
+            if t is not None:
+                out['%s_point_scores_list_%d' % (name, i)] = t.numpy()
+        for key in ('point_candidate_coords', 'point_vote_coords', 'batch_cls_preds', 'batch_box_preds', 'point_reg_preds',
+                    'vote_offsets'):
+            out[name + '_' + key] = bd[key].numpy()
+        # 512-wide features: keep a strided sample (the whole tensor is 0.5 MB per case)
+        out[name + '_point_features_s8'] = bd['point_features'].numpy()[:, ::8]
+        p = pred[0]
+        out[name + '_pred_boxes'] = p['pred_boxes'].numpy()
+        out[name + '_pred_scores'] = p['pred_scores'].numpy()
+        out[name + '_pred_labels'] = p['pred_labels'].numpy()
+        print("det6d_full %s: %d detections" % (name, len(p['pred_scores'])))
+    np.savez_compressed(os.path.join(HERE, "det6d_full.npz"), **out)
+    print("det6d_full.npz", os.path.getsize(os.path.join(HERE, "det6d_full.npz")), "bytes")
+
+
 # ----------------------------------------------------------------------------- input producer
 def producer_frame(seed, n, x_hi=80.0):
     """(n, 4) frame [x, y, z, id]: the last column is a unique id so rows can be traced"""
@@ -501,10 +571,7 @@ def gen_eval():
 if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
-    gen_nms()
-    gen_box_coder()
-    gen_model()
-    gen_producer()
-    gen_annos()
-    gen_slope()
-    gen_eval()
+    gens = dict(nms=gen_nms, box_coder=gen_box_coder, model=gen_model, producer=gen_producer, annos=gen_annos,
+                slope=gen_slope, eval=gen_eval, model_full=gen_model_full)
+    for name in (sys.argv[1:] or list(gens)):      # `python make_golden.py model_full` regenerates one fixture
+        gens[name]()

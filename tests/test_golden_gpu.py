@@ -63,3 +63,35 @@ def test_whole_model_against_reference_python_golden():
         np.testing.assert_array_equal(pred[i]['pred_labels'].cpu().numpy(), z['pred_labels_%d' % i])
         d = np.abs(got_b[None] - want_b[:, None]).max(-1)
         assert (d.min(axis=1) < 1e-4).all() and (d.min(axis=0) < 1e-4).all()
+
+
+@pytest.mark.parametrize("name", ["uniform", "beam"])
+def test_full_width_model_against_reference_python_golden(name):
+    """kitti_models/det6d_car.yaml — the benchmarked widths (K up to 1536) — one 16384-point scene per case, HIP path vs the
+    reference's own Python model (tests/golden/det6d_full.npz, make_golden.py: gen_model_full): sampled point sets of all
+    three levels identical (D-FPS and S-FPS picks), confidence scores, vote points, box codes, decoded boxes and class
+    logits within 1e-4 abs, kept detections the same set."""
+    from de6d_amd.runtime import load_config, build_model
+    from tests.test_oracle_golden import full_case_inputs
+    z = np.load(os.path.join(G, 'det6d_full.npz'))
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=int(z['weight_seed']), device='cuda')
+    bd = {'batch_size': 1, 'points': torch.from_numpy(full_case_inputs(z, name)).cuda()}
+    with torch.no_grad():
+        pred, _ = model(bd)
+    for lvl in range(3):
+        np.testing.assert_array_equal(bd['point_coords_list'][lvl].cpu().numpy()[:, 1:], z['%s_point_coords_list_%d' % (name, lvl)])
+    for lvl in (0, 1):
+        np.testing.assert_allclose(bd['point_scores_list'][lvl].cpu().numpy().reshape(-1),
+                                   z['%s_point_scores_list_%d' % (name, lvl)].reshape(-1), atol=1e-4)
+    np.testing.assert_allclose(bd['point_features'].cpu().numpy()[:, ::8], z[name + '_point_features_s8'], atol=1e-4)
+    for key in ('point_candidate_coords', 'point_vote_coords', 'batch_cls_preds', 'batch_box_preds', 'point_reg_preds',
+                'vote_offsets'):
+        np.testing.assert_allclose(bd[key].cpu().numpy(), z[name + '_' + key], atol=1e-4, err_msg=key)
+    want_b = z[name + '_pred_boxes']
+    got_b = pred[0]['pred_boxes'].cpu().numpy()
+    assert got_b.shape == want_b.shape
+    np.testing.assert_allclose(pred[0]['pred_scores'].cpu().numpy(), z[name + '_pred_scores'], atol=1e-5)
+    np.testing.assert_array_equal(pred[0]['pred_labels'].cpu().numpy(), z[name + '_pred_labels'])
+    d = np.abs(got_b[None] - want_b[:, None]).max(-1)
+    assert (d.min(axis=1) < 1e-4).all() and (d.min(axis=0) < 1e-4).all()

@@ -88,3 +88,56 @@ def test_whole_model_against_reference_python(oracle_ops):
         # the order: match every golden detection to an oracle detection instead of row-by-row
         d = np.abs(got['pred_boxes'][None, :, :] - want_b[:, None, :]).max(-1)
         assert (d.min(axis=1) < 1e-4).all() and (d.min(axis=0) < 1e-4).all()
+
+
+# ------------------------------------------------------------------------------------------ full width (det6d_car.yaml)
+def full_case_inputs(z, name):
+    """regenerates the scene of a det6d_full.npz case from its seed (tests/golden/make_golden.py: gen_model_full)"""
+    from tests import util as tutil
+    n = int(z['n'])
+    batch = getattr(tutil, str(z[name + '_generator']))(int(z[name + '_scene_seed']), 1, n, tilt=bool(z[name + '_tilt']))
+    return np.concatenate([np.zeros((n, 1), np.float32), batch.reshape(n, 4)], 1).astype(np.float32)
+
+
+def compare_full_case(z, name, got, tol=1e-4):
+    """got: dict in oracle/model.py's layout.  Returns the number of sampled points that differ from the reference's
+    (0 = identical S-FPS / D-FPS picks at all three levels); raises when a float quantity is off by more than tol."""
+    flips = 0
+    for lvl, xyz in enumerate(got['l_xyz']):
+        want = z['%s_point_coords_list_%d' % (name, lvl)]
+        flips += int((xyz.reshape(-1, 3) != want).any(axis=1).sum())
+    if flips:
+        return flips
+    for lvl in (0, 1):
+        np.testing.assert_allclose(got['l_scores'][lvl].reshape(-1), z['%s_point_scores_list_%d' % (name, lvl)].reshape(-1),
+                                   atol=tol, err_msg='confidence scores of level %d' % lvl)
+    np.testing.assert_allclose(got['point_features'][:, ::8], z[name + '_point_features_s8'], atol=tol)
+    np.testing.assert_array_equal(got['point_candidate_coords'], z[name + '_point_candidate_coords'][:, 1:])
+    np.testing.assert_allclose(got['point_vote_coords'], z[name + '_point_vote_coords'][:, 1:], atol=tol)
+    np.testing.assert_allclose(got['vote_offsets'], z[name + '_vote_offsets'].transpose(0, 2, 1).reshape(-1, 3), atol=tol)   # reference layout (B, 3, P)
+    np.testing.assert_allclose(got['batch_cls_preds'], z[name + '_batch_cls_preds'], atol=tol)
+    np.testing.assert_allclose(got['point_reg_preds'], z[name + '_point_reg_preds'], atol=tol)
+    np.testing.assert_allclose(got['batch_box_preds'], z[name + '_batch_box_preds'], atol=tol)
+    want_b, want_s = z[name + '_pred_boxes'], z[name + '_pred_scores']
+    pd = got['pred_dicts'][0]
+    assert pd['pred_boxes'].shape == want_b.shape
+    np.testing.assert_allclose(pd['pred_scores'], want_s, atol=1e-5)
+    np.testing.assert_array_equal(pd['pred_labels'], z[name + '_pred_labels'])
+    d = np.abs(pd['pred_boxes'][None, :, :] - want_b[:, None, :]).max(-1)
+    assert (d.min(axis=1) < tol).all() and (d.min(axis=0) < tol).all()
+    return 0
+
+
+@pytest.mark.parametrize("name", ["uniform", "beam"])
+def test_full_width_model_against_reference_python(oracle_ops, name):
+    """kitti_models/det6d_car.yaml (K up to 1536, the benchmarked widths), one 16384-point scene: oracle/model.py vs the
+    reference's own Python model.  North star: identical sampled point sets at all three levels (the S-FPS picks depend on
+    confidence scores that went through up to nine stacked layers), boxes / poses within 1e-4 abs."""
+    from de6d_amd.runtime import load_config, build_model
+    from oracle import model as omodel
+    z = np.load(os.path.join(G, 'det6d_full.npz'))
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=int(z['weight_seed']))
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    got = omodel.forward(cfg.MODEL, sd, full_case_inputs(z, name), 1)
+    assert compare_full_case(z, name, got) == 0
