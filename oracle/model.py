@@ -135,6 +135,49 @@ def sa_layer(sd, prefix, spec, xyz, feats, scores=None, new_xyz=None):
     return new_xyz, new_feats, new_scores, aux
 
 
+def fp_module(sd, prefix, n_layers, unknown, known, unknown_feats, known_feats):
+    """PointnetFPModule.forward (core/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:144-174):
+    three_nn -> 1 / (dist + 1e-8) normalised over the three neighbours -> three_interpolate -> cat with the skip features
+    -> shared Conv2d/BN/ReLU stack (folded, ascending-k fma chains).  unknown (B,n,3), known (B,m,3),
+    unknown_feats (B,C1,n) | None, known_feats (B,C2,m) -> (B,C',n)"""
+    d2, idx = ops.three_nn(unknown, known)
+    dist = np.sqrt(d2).astype(F32)                                   # ThreeNN.forward returns sqrt(dist2) (pointnet2_utils.py:206)
+    recip = (F32(1.0) / (dist + F32(1e-8))).astype(F32)
+    norm = ((recip[:, :, 0] + recip[:, :, 1]) + recip[:, :, 2]).astype(F32)[:, :, None]
+    weight = (recip / norm).astype(F32)
+    interpolated = ops.three_interpolate(np.ascontiguousarray(known_feats), idx, np.ascontiguousarray(weight))
+    feats = interpolated if unknown_feats is None else np.concatenate([interpolated, unknown_feats], axis=1)
+    b, c, n = feats.shape
+    x = np.ascontiguousarray(feats.transpose(0, 2, 1)).reshape(b * n, c)
+    y = _chain(x, _stack(sd, prefix + '.mlp', n_layers))
+    return np.ascontiguousarray(y.reshape(b, n, -1).transpose(0, 2, 1))
+
+
+def backbone_forward(backbone_cfg, sd, points, batch_size, prefix='backbone_3d'):
+    """PointNet2FSMSG.forward incl. the feature-propagation branch (pointnet2_backbone.py:199-263): returns
+    dict(l_xyz, l_features, l_scores, point_features (B*N', C), point_xyz (B, N', 3))"""
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    pts = np.asarray(points, F32)
+    n = pts.shape[0] // batch_size
+    xyz = np.ascontiguousarray(pts[:, 1:4].reshape(batch_size, n, 3))
+    feats = np.ascontiguousarray(pts[:, 4:].reshape(batch_size, n, -1).transpose(0, 2, 1)) if pts.shape[1] > 4 else None
+    l_xyz, l_feats, l_scores = [xyz], [feats], [None]
+    pre = prefix + '.' if prefix else ''
+    for k, spec in enumerate(backbone_specs({'BACKBONE_3D': backbone_cfg})):
+        nx, nf, ns, _ = sa_layer(sd, '%sSA_modules.%d' % (pre, k), spec, l_xyz[-1], l_feats[-1], l_scores[-1])
+        l_xyz.append(nx); l_feats.append(nf); l_scores.append(ns)
+    fp = backbone_cfg.get('FP_MLPS', None)
+    i = 0
+    if fp is not None:
+        for i in range(-1, -(len(fp) + 1), -1):
+            l_feats[i - 1] = fp_module(sd, '%sFP_modules.%d' % (pre, i + len(fp)), len(fp[i + len(fp)]), l_xyz[i - 1], l_xyz[i],
+                                       l_feats[i - 1], l_feats[i])
+    out_feats = l_feats[i - 1]
+    b, c, m = out_feats.shape
+    return dict(l_xyz=l_xyz, l_features=l_feats, l_scores=l_scores, point_xyz=l_xyz[i - 1],
+                point_features=np.ascontiguousarray(out_feats.transpose(0, 2, 1)).reshape(b * m, c))
+
+
 def backbone_specs(model_cfg):
     sa = model_cfg['BACKBONE_3D']['SA_CONFIG']
     agg = sa.get('AGGREGATION_MLPS', None)

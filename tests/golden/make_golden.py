@@ -329,6 +329,75 @@ def gen_model_full():
     print("det6d_full.npz", os.path.getsize(os.path.join(HERE, "det6d_full.npz")), "bytes")
 
 
+# ----------------------------------------------------------------------------- feature propagation, boxes_iou3d_gpu
+from tests.golden.fp_config import FP_BACKBONE  # noqa: E402
+
+
+def gen_fp():
+    """fp.npz: (a) the reference's PointNet2FSMSG WITH feature propagation (pointnet2_backbone.py:178-191,249-255 ->
+    PointnetFPModule.forward, pointnet2_modules.py:144-174: three_nn, inverse-distance weights, three_interpolate,
+    cat with the skip features, shared Conv2d/BN/ReLU) on a seeded 2 x 2048 scene, torch-CPU math, oracle ops behind the
+    extension names; (b) the reference's boxes_iou3d_gpu (iou3d_nms_utils.py:48-81) on seeded boxes."""
+    EasyDict = install_reference_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pcdet.models.backbones_3d.pointnet2_backbone import PointNet2FSMSG as RefBackbone
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as ref_iou
+    import pcdet
+    assert pcdet.__file__.startswith(REF)
+    from de6d_amd.pcdet.models.backbones_3d.pointnet2_backbone import PointNet2FSMSG as OurBackbone
+    from de6d_amd.pcdet.config import EasyDict as OurEasyDict
+    from de6d_amd.runtime import randomize_bn_stats
+    torch.manual_seed(77)
+    ours = OurBackbone(OurEasyDict(FP_BACKBONE), input_channels=4)
+    with torch.no_grad():
+        randomize_bn_stats(ours)
+    sd = ours.state_dict()
+    ref = RefBackbone(EasyDict(FP_BACKBONE), input_channels=4)
+    assert list(ref.state_dict().keys()) == list(sd.keys())
+    ref.load_state_dict(sd)
+    ref.eval()
+    b, n, seed = 2, 2048, 910
+    batch = make_batch(seed, b, n)
+    pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
+    bd = {'batch_size': b, 'points': torch.from_numpy(pts)}
+    with torch.no_grad():
+        bd = ref(bd)
+    out = dict(weight_seed=np.int64(77), scene_seed=np.int64(seed), b=np.int64(b), n=np.int64(n),
+               point_features=bd['point_features'].numpy(), point_coords=bd['point_coords'].numpy(),
+               num_point_features=np.int64(ref.num_point_features))
+    for i, t in enumerate(bd['point_coords_list']):
+        out['point_coords_list_%d' % i] = t.numpy()
+    # stand-alone module: 3 known points or fewer than 3 distinct ones, no skip features
+    from pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import PointnetFPModule as RefFP
+    from de6d_amd.pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import PointnetFPModule as OurFP
+    torch.manual_seed(78)
+    ofp = OurFP(mlp=[12, 20, 8])
+    with torch.no_grad():
+        randomize_bn_stats(ofp)
+    rfp = RefFP(mlp=[12, 20, 8])
+    rfp.load_state_dict(ofp.state_dict())
+    rfp.eval()
+    rng = np.random.default_rng(5)
+    unknown = rng.uniform(-3, 3, (2, 300, 3)).astype(np.float32)
+    known = rng.uniform(-3, 3, (2, 40, 3)).astype(np.float32)
+    known[1, 5] = known[1, 4]                      # duplicate known points: equal distances
+    unknown[0, 7] = known[0, 3]                    # an unknown point ON a known one: dist 0, weight ~ 1
+    kf = rng.normal(size=(2, 12, 40)).astype(np.float32)
+    with torch.no_grad():
+        y = rfp(torch.from_numpy(unknown), torch.from_numpy(known), None, torch.from_numpy(kf))
+    out.update(fp_unknown=unknown, fp_known=known, fp_known_feats=kf, fp_out=y.numpy(), fp_seed=np.int64(78))
+    boxes_a = random_boxes(31, 40, spread=12.0)
+    boxes_b = random_boxes(32, 50, spread=12.0)
+    boxes_b[:5] = boxes_a[:5]
+    boxes_b[5, 2] += 10.0                          # no height overlap
+    out.update(iou3d_a=boxes_a, iou3d_b=boxes_b,
+               iou3d=ref_iou.boxes_iou3d_gpu(torch.from_numpy(boxes_a), torch.from_numpy(boxes_b)).numpy(),
+               iou_bev=ref_iou.boxes_iou_bev(torch.from_numpy(boxes_a), torch.from_numpy(boxes_b)).numpy())
+    np.savez_compressed(os.path.join(HERE, "fp.npz"), **out)
+    print("fp.npz", os.path.getsize(os.path.join(HERE, "fp.npz")), "bytes; features", out['point_features'].shape)
+
+
 # ----------------------------------------------------------------------------- input producer
 def producer_frame(seed, n, x_hi=80.0):
     """(n, 4) frame [x, y, z, id]: the last column is a unique id so rows can be traced"""
@@ -572,6 +641,6 @@ if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
     gens = dict(nms=gen_nms, box_coder=gen_box_coder, model=gen_model, producer=gen_producer, annos=gen_annos,
-                slope=gen_slope, eval=gen_eval, model_full=gen_model_full)
+                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, fp=gen_fp)
     for name in (sys.argv[1:] or list(gens)):      # `python make_golden.py model_full` regenerates one fixture
         gens[name]()
