@@ -279,7 +279,7 @@ def family_saturated(replay, n_streams=16, reps=24, streams=None):
     return {"seconds": time.perf_counter() - t0, "passes": n_streams * reps, "streams": n_streams, "replays": reps}
 
 
-def linear_roofline(model, points, batch, flops_per_scene, streams=None):
+def linear_roofline(model, points, batch, flops_per_scene, streams=None, pmc_tag='uniform'):
     """average achieved TFLOP/s of the dominant kernel family (linear_kernel + the register chain kernels: the
     SA / head MLP GEMMs) measured live with HIP events on the launch stream over one PASS (`batch` scenes: the launches
     the pipeline issues, i.e. --merge batches of 8 scenes per launch).
@@ -323,7 +323,11 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
     dense = flops_per_scene * batch
     achieved = useful / (total_ms * 1e-3) / 1e12
     traffic = None
-    pmc = sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')))
+    # committed PMC summaries: profiles/rNN_<tag>_pmc_summary.json with tag "beam" for the ray-cast scenes
+    pmc = sorted(f for f in __import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json'))
+                 if ('beam' in os.path.basename(f)) == (pmc_tag == 'beam'))
+    if os.environ.get('DET6D_DENSE_ROWS'):
+        pmc = []
     if pmc:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
         try:
             traffic = round(json.load(open(pmc[-1]))['_derived']['linear_kernel']['hbm_bytes_per_launch'])
@@ -358,7 +362,7 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None):
             "kernel_ms_per_pass": round(total_ms, 3)}
 
 
-def child_rate(args, env_extra, extra_args=(), note=""):
+def child_rate(args, env_extra, extra_args=(), note="", roofline=False):
     """the same bench (same steps / warmup / pipeline shape) in a child process with another switch or workload; the
     parent's GPU state is untouched (the child is a fresh process, nothing is exec'd from this one)"""
     import subprocess
@@ -367,15 +371,20 @@ def child_rate(args, env_extra, extra_args=(), note=""):
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
            '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--worker', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
            '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch), '--merge', str(args.merge),
-           '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + list(extra_args)
+           '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + (['--leg-roofline'] if roofline else []) + list(extra_args)
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res = {"scenes_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
                "selfcheck": d.get("selfcheck"), "cold_scenes_per_s": d.get("cold", {}).get("scenes_per_s"),
-               "latency_ms_per_batch": d.get("latency", {}).get("ms_per_batch")}
+               "latency_ms_per_batch": d.get("latency", {}).get("ms_per_batch"),
+               "latency_under_load_ms": d.get("latency_under_load", {}).get("ms_p50_p99"),
+               "window_ms_min_median_max": d.get("config", {}).get("window_ms_min_median_max")}
         if d.get("compact_fill"):
             res["compact_fill"] = {g["group"]: g["fill"] for g in d["compact_fill"]}
+        if d.get("roofline"):            # the leg's own GEMM-family roofline (its own flop count: the balls' fill differs)
+            res["algorithmic_gflop_per_pass"] = d["roofline"]["algorithmic_gflop_per_pass"]
+            res["roofline"] = d["roofline"]
         if note:
             res["note"] = note
         return res
@@ -449,7 +458,7 @@ def orchestrate(args):
         return out.returncode or 1
     line = json.loads(lines[-1])
     if os.environ.get('DET6D_DENSE_ROWS') is None:
-        line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'},
+        line["dense_rows"] = child_rate(args, {'DET6D_DENSE_ROWS': '1'}, roofline=not args.no_roofline,
                                         note="DET6D_DENSE_ROWS=1: every (centre, nsample slot) row evaluated, as the reference does; "
                                              "the bound for clouds whose every ball is full")
         if args.merge > 1:
@@ -468,7 +477,13 @@ def orchestrate(args):
             ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
             ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
         ]
-        line["other_configs"] = {name: child_rate(args, {}, extra) for name, extra in legs}
+        line["other_configs"] = {name: child_rate(args, {}, extra, roofline=not args.no_roofline and '--scene' in extra)
+                                 for name, extra in legs}
+        # the reference's timed loop includes load_data_to_gpu (core/tools/eval_utils/eval_utils.py:53-56): the same stream of
+        # steps with every batch uploaded from pinned host memory on its pass's sampler stream.  Never `value`.
+        line["h2d_inclusive"] = child_rate(args, {}, ['--h2d'],
+                                           note="--h2d: every step uploads its %d x %d x 5 floats from pinned host memory (PCIe) before "
+                                                "its pass; reported beside `value`, never as `value`" % (args.batch, args.points))
     print(json.dumps(line), flush=True)
     return 0
 
@@ -523,6 +538,7 @@ def main():
     ap.add_argument('--preroll', type=int, default=-1, help='pre-roll length in pipeline capacities (default 8)')
     ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes timed on the CPU oracle (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--leg-roofline', action='store_true', help='(internal) a child leg that reports its own GEMM-family roofline')
     ap.add_argument('--no-legs', action='store_true', help='skip the child-process legs (dense rows, other BASELINE configs)')
     ap.add_argument('--worker', action='store_true', help='(internal) the measuring process started by the orchestrating parent')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
@@ -549,6 +565,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count() and os.environ.get('DET6D_BENCH_BACKEND') != 'gloo':
+        raise SystemExit("bench.py: LOCAL_RANK %d but %d visible device(s): one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
     ranks_seen = [device_identity()]
@@ -560,6 +578,10 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, device_identity())
+        if len(set(ranks_seen)) != world and backend != 'gloo':
+            # `--gpus N` on a box with fewer devices would report n_gpus = N from ranks sharing a GPU
+            raise SystemExit("bench.py: %d ranks but only %d distinct devices %s (DET6D_BENCH_BACKEND=gloo allows a dry run on "
+                             "shared devices)" % (world, len(set(ranks_seen)), sorted(set(ranks_seen))))
 
     cfg = load_config(args.cfg)
     model = build_model(cfg, seed=1234, device='cuda')
@@ -650,12 +672,14 @@ def main():
     tail = capacity
     first = preroll + args.warmup - 1
     last = first + (n_windows - 1) * k + args.steps
-    stamps, dets = {}, [0]
+    stamps, dets, issued = {}, [0], {}
     device_clock = not args.no_graph       # completion times from the device (one timing event per pass) instead of the host
 
     def on_done(step, r, preds):
         if step <= last:
             stamps[step] = r.stamp if device_clock else time.perf_counter()
+            if device_clock:
+                issued[step] = r.issued_at
         if first < step <= first + args.steps:
             dets[0] += sum(len(p['pred_scores']) for p in preds)
 
@@ -664,7 +688,8 @@ def main():
     GraphedDet6D.stamp_launches = device_clock
     origin = torch.cuda.Event(enable_timing=True)
     origin.record()
-    t_stream = time.perf_counter()
+    origin.synchronize()                   # the device is idle here: the event's device time == this host time (to ~10 us)
+    t_origin = t_stream = time.perf_counter()
     run(last + 1 + tail, on_done)
     bracket()
     t_stream = time.perf_counter() - t_stream
@@ -678,6 +703,15 @@ def main():
             t_run = max(t_run, origin.elapsed_time(stamps[s_]) * 1e-3)
             delivered[s_] = t_run
         stamps = delivered
+        # per-step latency under load: from the host call that issued the step's pass (stage 1: pack + input-only samplers)
+        # to the step's in-order delivery on the device; steps of the timed windows only
+        lat = sorted(delivered[s_] - (issued[s_] - t_origin) for s_ in delivered if first < s_ <= last)
+        latency_under_load = {"ms_p50_p99": [round(lat[len(lat) // 2] * 1e3, 2), round(lat[min(len(lat) - 1, int(0.99 * len(lat)))] * 1e3, 2)],
+                              "ms_min_max": [round(lat[0] * 1e3, 2), round(lat[-1] * 1e3, 2)], "steps": len(lat),
+                              "note": "host issue of the step's pass (sampler stage, issued %d group(s) ahead of the GEMM stage) -> "
+                                      "in-order delivery of the step on the device clock, with the pipeline full" % args.prefetch}
+    else:
+        latency_under_load = None
     windows = sorted(stamps[first + j * k + args.steps] - stamps[first + j * k] for j in range(n_windows))
     window_median = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
     elapsed_own = sum(windows) / len(windows)
@@ -751,6 +785,8 @@ def main():
             "cold": {"scenes_per_s": round(world * args.steps * b / cold, 2), "ms_per_step": round(cold / args.steps * 1e3, 4),
                      "note": "the same %d steps on an empty pipeline, barrier+synchronize on both sides: pipeline fill + drain included" % args.steps},
         }
+        if latency_under_load is not None:
+            line["latency_under_load"] = latency_under_load
         if world == 1:
             lat = GraphedDet6D(model, b, n, points=points)
             lat.launch(); lat.finalize()
@@ -770,6 +806,10 @@ def main():
             pipe = None  # noqa: F841  (frees the captured graphs before the pipeline leg builds its own)
             torch.cuda.empty_cache()
             line["pipeline"] = pipeline_rate(cfg, model, b * merge, n, group=args.group, n_main=depth, prefetch=args.prefetch)
+        elif world == 1 and args.leg_roofline:
+            line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS, pmc_tag=args.scene)
+            line["roofline"]["scenes_per_pass"] = b * merge
+            line["compact_fill"] = compact_fill(model, points, b)
         elif world == 1:
             line["compact_fill"] = compact_fill(model, points, b)
         if world == 1 and args.cpu_scenes > 0:

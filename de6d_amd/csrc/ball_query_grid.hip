@@ -6,12 +6,9 @@
 // neighbouring columns of a uniform (x, y) grid whose cell edge is >= the outer radius, instead of
 // sweeping all N points.
 //
-// The reference's "first nsample by index" contract forbids visiting candidates in spatial order, so
-// the query is split in two exact steps:
-//   1. every candidate of the 3x3 neighbourhood that passes a shell test sets bit k of a per-wave
-//      N-bit LDS bitmap (ds_or_b32) — order-free;
-//   2. the bitmap is read back in ascending word/bit order with a wave prefix-popcount, which yields
-//      the hits sorted by index; the first nsample are kept.
+// The reference's "first nsample by index" contract forbids taking candidates in spatial order: per shell the
+// query keeps a running selection of the nsample smallest hit indices in a short LDS list with a pruning
+// threshold (bq_grid_query_kernel below) and ranks it once at the end.
 // The distance arithmetic per (centre, point) pair is the same fma chain as everywhere else, so hit
 // sets are bit-identical to the brute-force kernels'.
 //
@@ -25,7 +22,7 @@ constexpr int kGridMax = 128;                 // cells per axis
 constexpr int kGridCells = kGridMax * kGridMax;
 constexpr int kBuildThreads = 1024;
 constexpr int kQueryWaves = 4;
-constexpr int kMaxNs = 128;
+constexpr int kMaxNs = 64;                    // nsample of a shell: one list entry per lane when the list is ranked
 
 struct GridHeader {   // per scene, 32 bytes
   float ox, oy, inv_cell;
@@ -135,24 +132,56 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
   }
 }
 
-// one wave per centre; bitmaps of N bits per shell per wave in dynamic LDS
+// Keeps the min(n, ns) SMALLEST entries of lst[0..n) (n <= kListCap, distinct point indices), ascending, in lst[0..); returns
+// how many.  One or two entries per lane, each finds its rank among the others (LDS broadcast reads).
+__device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restrict__ tmp, int n, int ns, int lane) {
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  const int e0 = lane < n ? lst[lane] : 0x7fffffff;
+  const int e1 = lane + 64 < n ? lst[lane + 64] : 0x7fffffff;
+  int r0 = 0, r1 = 0;
+  if (n <= 64) {
+    for (int j = 0; j < n; ++j) r0 += lst[j] < e0;
+  } else {
+    for (int j = 0; j < n; ++j) { const int v = lst[j]; r0 += v < e0; r1 += v < e1; }
+  }
+  if (lane < n && r0 < ns) tmp[r0] = e0;
+  if (lane + 64 < n && r1 < ns) tmp[r1] = e1;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  const int keep = n < ns ? n : ns;
+  if (lane < keep) lst[lane] = tmp[lane];          // ns <= 64
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  return keep;
+}
+
+// One wave per centre.  The reference's contract is "the first nsample hits by ASCENDING POINT INDEX", but the grid hands
+// out candidates in spatial order, so per shell the wave keeps a running selection of the nsample smallest hit indices:
+// hits are appended, unordered, to a kListCap-entry LDS list through ballots; when the list would overflow it is cut back
+// to its nsample smallest entries and the largest of them becomes a THRESHOLD — a later hit with a larger index can never
+// be among the first nsample and is dropped before it is stored.  After the first cut the list holds >= nsample entries for
+// good, so the hit count min(total, nsample) is known without counting the dropped hits.  On FPS-sampled clouds a shell has
+// a handful of hits and the list is ranked once, at the end; in the dense parts of a real sweep (hundreds of hits in the
+// 0.8 m shell of the first SA layer) a cut happens once or twice per centre.  (Round 2 re-scanned such centres into an
+// N-bit LDS bitmap per wave and read it back in index order: 273 us for SA1 on ray-cast scenes against 31 us on uniform
+// ones; bit-identical results.)
+constexpr int kListCap = 128;
+
 __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
-    int n, int m, int words, float rin2_a, float rout2_a, int ns_a, float rin2_b, float rout2_b, int ns_b,
-    const float *__restrict__ new_xyz, const float *__restrict__ xyz, const GridHeader *__restrict__ hdr,
+    int n, int m, float rin2_a, float rout2_a, int ns_a, float rin2_b, float rout2_b, int ns_b,
+    const float *__restrict__ new_xyz, const GridHeader *__restrict__ hdr,
     const int *__restrict__ cell_start, const float4 *__restrict__ sorted_pts, int *__restrict__ cnt_a,
     int *__restrict__ idx_a, int *__restrict__ cnt_b, int *__restrict__ idx_b) {
-  extern __shared__ unsigned bitmaps[];            // [kQueryWaves][2][words]
-  __shared__ int hits[kQueryWaves][2][kMaxNs];
-  __shared__ int lists[kQueryWaves][2][64];
+  __shared__ int lists[kQueryWaves][2][kListCap];
+  __shared__ int tmp[kQueryWaves][kMaxNs];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bs = blockIdx.y;
-  unsigned *bm_a = bitmaps + (size_t)(wave * 2 + 0) * words;
-  unsigned *bm_b = bitmaps + (size_t)(wave * 2 + 1) * words;
-  for (int w = lane; w < words; w += 64) { bm_a[w] = 0u; bm_b[w] = 0u; }
   const GridHeader h = hdr[bs];
   const int *cs = cell_start + (size_t)bs * (kGridCells + 1);
   const float4 *si = sorted_pts + (size_t)bs * n;
-  const int wpl = (words + 63) / 64;               // bitmap words per lane (contiguous block per lane)
+  int *la = lists[wave][0], *lb = lists[wave][1], *tw = tmp[wave];
+  const unsigned long long below = (1ull << lane) - 1ull;
 
   for (int ci = blockIdx.x * kQueryWaves + wave; ci < m; ci += gridDim.x * kQueryWaves) {
     const float *q = new_xyz + ((size_t)bs * m + ci) * 3;
@@ -160,14 +189,8 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
     const int cx = cell_coord(qx, h.ox, h.inv_cell, h.nx), cy = cell_coord(qy, h.oy, h.inv_cell, h.ny);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.nx - 1);
     const int y0 = max(cy - 1, 0), y1 = min(cy + 1, h.ny - 1);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    // 1a. short lists: the hits of a centre (a handful on FPS-sampled clouds) are appended, unordered, to one 64-entry
-    //     list per shell through ballots; each hit then finds its rank by index among the others (one lane per hit,
-    //     an LDS broadcast read per other hit) — the "first nsample by ascending index" contract without touching the
-    //     N-bit bitmaps.  A shell with more than 64 hits falls back to the bitmap path below for this centre.
-    int na = 0, nb = 0;
-    int *la = lists[wave][0], *lb = lists[wave][1];
+    int na = 0, nb = 0;                              // entries in the lists (wave-uniform)
+    int thr_a = 0x7fffffff, thr_b = 0x7fffffff;      // only hits with a smaller point index can still be among the first nsample
     for (int y = y0; y <= y1; ++y) {
       const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];   // x-contiguous cells: one range
       for (int t0 = beg; t0 < end; t0 += 64) {
@@ -178,85 +201,39 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
           const float4 c = si[t];
           k = __float_as_int(c.w);
           const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
-          ha = d2 >= rin2_a && d2 < rout2_a;
-          hb = d2 >= rin2_b && d2 < rout2_b;
+          ha = d2 >= rin2_a && d2 < rout2_a && k < thr_a;
+          hb = d2 >= rin2_b && d2 < rout2_b && k < thr_b;
         }
-        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (ha) { const int pos = na + __popcll(ma & below); if (pos < 64) la[pos] = k; }
-        if (hb) { const int pos = nb + __popcll(mb & below); if (pos < 64) lb[pos] = k; }
+        unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        if (na + __popcll(ma) > kListCap) {          // wave-uniform: cut the list back to its ns_a smallest entries
+          na = keep_smallest(la, tw, na, ns_a, lane);
+          thr_a = la[ns_a - 1];                      // na == ns_a here (the list held more than 64 >= ns_a entries)
+          ha = ha && k < thr_a;
+          ma = __ballot(ha);
+        }
+        if (nb + __popcll(mb) > kListCap) {
+          nb = keep_smallest(lb, tw, nb, ns_b, lane);
+          thr_b = lb[ns_b - 1];
+          hb = hb && k < thr_b;
+          mb = __ballot(hb);
+        }
+        if (ha) la[na + __popcll(ma & below)] = k;
+        if (hb) lb[nb + __popcll(mb & below)] = k;
         na += __popcll(ma);
         nb += __popcll(mb);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    if (na <= 64 && nb <= 64) {
-#pragma unroll
-      for (int sh = 0; sh < 2; ++sh) {
-        const int *lst = sh == 0 ? la : lb;
-        const int total = sh == 0 ? na : nb;
-        const int ns = sh == 0 ? ns_a : ns_b;
-        int *hbuf = hits[wave][sh];
-        const int mine = lane < total ? lst[lane] : 0x7fffffff;
-        int rank = 0;
-        for (int j = 0; j < total; ++j) rank += lst[j] < mine;      // point indices are distinct
-        if (lane < total && rank < ns) hbuf[rank] = mine;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        const int cnt = min(total, ns);
-        int *out = (sh == 0 ? idx_a : idx_b) + ((size_t)bs * m + ci) * ns;
-        if (lane == 0) (sh == 0 ? cnt_a : cnt_b)[(size_t)bs * m + ci] = cnt;
-        for (int l = lane; l < ns; l += 64) out[l] = cnt > 0 ? hbuf[l % cnt] : 0;
-      }
-      continue;
-    }
-    // 1b. (more than 64 hits in a shell) mark hits in the bitmaps (order-free)
-    for (int y = y0; y <= y1; ++y) {
-      const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];
-      for (int t = beg + lane; t < end; t += 64) {
-        const float4 c = si[t];
-        const int k = __float_as_int(c.w);
-        const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
-        if (d2 >= rin2_a && d2 < rout2_a) atomicOr(&bm_a[k >> 5], 1u << (k & 31));
-        if (d2 >= rin2_b && d2 < rout2_b) atomicOr(&bm_b[k >> 5], 1u << (k & 31));
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    // 2. read the bitmaps back in index order
 #pragma unroll
     for (int sh = 0; sh < 2; ++sh) {
-      unsigned *bm = sh == 0 ? bm_a : bm_b;
+      int *lst = sh == 0 ? la : lb;
       const int ns = sh == 0 ? ns_a : ns_b;
-      int *hb = hits[wave][sh];
-      const int w0 = lane * wpl, w1 = min(w0 + wpl, words);
-      int mine = 0;
-      for (int w = w0; w < w1; ++w) mine += __popc(bm[w]);
-      int incl = mine;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      const int total = __shfl(incl, 63);
-      int rank = incl - mine;
-      for (int w = w0; w < w1; ++w) {
-        unsigned bits = bm[w];
-        if (bits) bm[w] = 0u;                       // leave the bitmap clean for the next centre
-        while (bits && rank < ns) {
-          const int bit = __builtin_ctz(bits);
-          bits &= bits - 1;
-          hb[rank++] = (w << 5) + bit;
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_wave_barrier();
-      const int cnt = min(total, ns);
+      const int cnt = keep_smallest(lst, tw, sh == 0 ? na : nb, ns, lane);   // = min(total hits, ns): see the header
       int *out = (sh == 0 ? idx_a : idx_b) + ((size_t)bs * m + ci) * ns;
       if (lane == 0) (sh == 0 ? cnt_a : cnt_b)[(size_t)bs * m + ci] = cnt;
-      for (int l = lane; l < ns; l += 64) out[l] = cnt > 0 ? hb[l % cnt] : 0;
+      for (int l = lane; l < ns; l += 64) out[l] = cnt > 0 ? lst[l % cnt] : 0;
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();                 // the lists are rewritten by the next centre
   }
 }
 
@@ -275,9 +252,6 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
   if (b < 0 || n <= 0 || m < 0 || ns_a <= 0 || ns_b <= 0 || ns_a > kMaxNs || ns_b > kMaxNs || !new_xyz || !xyz ||
       !workspace || ((uintptr_t)workspace & 15) || !cnt_a || !idx_a || !cnt_b || !idx_b)
     return DET6D_EINVAL;
-  const int words = (n + 31) / 32;
-  const size_t lds = (size_t)kQueryWaves * 2 * words * sizeof(unsigned);
-  if (lds > 96 * 1024) return DET6D_EINVAL;        // N <= 98304; use det6d_ball_query_pair beyond
   if (b == 0 || m == 0) return DET6D_OK;
   hipStream_t s = (hipStream_t)stream;
   // workspace layout: headers | cell_start | sorted (x, y, z, index) records
@@ -288,18 +262,11 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
   off += ((size_t)b * (kGridCells + 1) * 4 + 63) / 64 * 64;
   float4 *sorted_pts = (float4 *)(ws + off);
   const float rmax = rout_a > rout_b ? rout_a : rout_b;
-  static bool big_lds = false;
-  if (lds > 32 * 1024 && !big_lds) {
-    hipError_t e = hipFuncSetAttribute((const void *)bq_grid_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       96 * 1024);
-    if (e != hipSuccess) { det6d_set_error("det6d_ball_query_pair_grid hipFuncSetAttribute", e); return DET6D_ELAUNCH; }
-    big_lds = true;
-  }
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start,
                      sorted_pts);
   const int blocks_x = min(det6d_divup(m, kQueryWaves), 1024);
-  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks_x, b), dim3(64 * kQueryWaves), lds, s, n, m, words,
-                     rin_a * rin_a, rout_a * rout_a, ns_a, rin_b * rin_b, rout_b * rout_b, ns_b, new_xyz, xyz, hdr,
+  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks_x, b), dim3(64 * kQueryWaves), 0, s, n, m,
+                     rin_a * rin_a, rout_a * rout_a, ns_a, rin_b * rin_b, rout_b * rout_b, ns_b, new_xyz, hdr,
                      cell_start, sorted_pts, cnt_a, idx_a, cnt_b, idx_b);
   return det6d_check_launch("det6d_ball_query_pair_grid");
 }

@@ -526,6 +526,7 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream);
 
 int det6d_fps_coop_status(int b, int n, const void *workspace, hipStream_t stream);
+long long det6d_fps_coop_status_offset(int b, int n);
 
 DET6D_API int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream) {
   if (!temp || !det6d_fps_coop_handles(n)) return DET6D_OK;     // only the cooperative sampler can fail after its launch
@@ -533,6 +534,14 @@ DET6D_API int det6d_fps_fused_status(int b, int n, const float *temp, long long 
   const long long need = det6d_fps_coop_workspace_bytes(b, n);
   if (need <= 0 || temp_bytes - (ws - reinterpret_cast<const char *>(temp)) < need) return DET6D_OK;
   return det6d_fps_coop_status(b, n, ws, (hipStream_t)stream);
+}
+
+DET6D_API long long det6d_fps_fused_status_offset(int b, int n, const float *temp, long long temp_bytes) {
+  if (!temp || !det6d_fps_coop_handles(n)) return -1;
+  const char *ws = reinterpret_cast<const char *>(((uintptr_t)temp + 255) & ~(uintptr_t)255);
+  const long long need = det6d_fps_coop_workspace_bytes(b, n);
+  if (need <= 0 || temp_bytes - (ws - reinterpret_cast<const char *>(temp)) < need) return -1;
+  return (ws - reinterpret_cast<const char *>(temp)) + det6d_fps_coop_status_offset(b, n);
 }
 
 DET6D_API long long det6d_fps_fused_workspace_bytes(int b, int n) {

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(1024) void coop_keys_kernel(int n, long long xyz_bs
     vals[(size_t)scene * n + k] = (unsigned)k;
   }
   for (int w = tid; w < exch_words; w += 1024) exch[(size_t)scene * exch_words + w] = 0ull;
-  if (scene == 0 && tid == 0) *err = 0;
+  // the error word is STICKY: it is cleared when the workspace is created (zero-filled by the caller) and by
+  // det6d_fps_fused_status once it has been read, never by a launch — a later launch must not hide an earlier failure
+  (void)err;
 }
 
 // ---- pre-pass 2: the 16 points of a lane ordered by the reference's tie key (strict '>' of the scan keeps the right one)
@@ -132,7 +134,7 @@ template <int PARTS>
 __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int log2s, long long xyz_bstride,
                                                         long long idx_bstride, int idx_add, const float *__restrict__ xyz,
                                                         const unsigned *__restrict__ perm, int *__restrict__ idxs,
-                                                        unsigned long long *__restrict__ exch, int *err) {
+                                                        unsigned long long *__restrict__ exch, int *err, int force_agent) {
   constexpr int NW = 16, SLOTS = 16, HG = SLOTS / 2;
   __shared__ float4 slot_v[2][NW];
   __shared__ int slot_k[2][NW];
@@ -194,11 +196,12 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
       if (__ballot(!ok) == 0ull) break;
       if (++spins0 > (1 << 22)) {
         if (lane == 0) atomicExch(err, 1);
+        if (part == 0) for (int i = 1 + h; i < m; i += 1024) idxs[i] = idx_add;   // in-range picks: nothing downstream may fault
         return;
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    same_xcd = __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;
+    same_xcd = !force_agent && __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;
   }
   float cg_val = __builtin_inff(), cg_x = 0.f, cg_y = 0.f, cg_z = 0.f;
   int cg_k = 0;
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
     }
     if (dead) {
       if (lane == 0) atomicExch(err, 1);
+      if (part == 0) for (int i = r + h; i < m; i += 1024) idxs[i] = idx_add;     // in-range picks: nothing downstream may fault
       return;
     }
     const unsigned pay = (unsigned)word;
@@ -370,16 +374,25 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   const long long groups = (long long)b * n / 16;
   hipLaunchKernelGGL(coop_group_order_kernel, dim3((unsigned)((groups + 511) / 512)), dim3(512), 0, stream, groups, n, log2s, vals_out);
   const int grid = 8 * parts * ((b + 7) / 8);
+  // DET6D_FPS_COOP_AGENT=1: agent-scope publishing stores also when the parts of a scene share an XCD (see same_xcd)
+  static const int force_agent = det6d_switch_set("DET6D_FPS_COOP_AGENT") ? 1 : 0;
   if (parts == 4)
     hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err);
+                       vals_out, idx, exch, err, force_agent);
   else
     hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err);
+                       vals_out, idx, exch, err, force_agent);
   return det6d_check_launch("det6d_fps (cooperative)");
 }
 
-// error word of the last cooperative launch on `workspace` (synchronises `stream`): 0 = fine
+// byte offset of the (sticky) error word inside a cooperative workspace
+long long det6d_fps_coop_status_offset(int b, int n) {
+  if (!det6d_fps_coop_handles(n) || b <= 0 || b > 4096) return -1;
+  return (long long)coop_layout(b, n).err;
+}
+
+// error word of the cooperative launches on `workspace` since it was last read (synchronises `stream`): 0 = fine.  Reading a
+// set word clears it.
 int det6d_fps_coop_status(int b, int n, const void *workspace, hipStream_t stream) {
   if (!det6d_fps_coop_handles(n) || b <= 0 || b > 4096 || !workspace) return DET6D_EINVAL;
   const CoopLayout L = coop_layout(b, n);
@@ -388,6 +401,7 @@ int det6d_fps_coop_status(int b, int n, const void *workspace, hipStream_t strea
       hipStreamSynchronize(stream) != hipSuccess)
     return DET6D_ELAUNCH;
   if (flag) {
+    hipMemsetAsync((char *)workspace + L.err, 0, sizeof(int), stream);
     det6d_set_error("det6d_fps (cooperative): a workgroup waited > 2 s for its partners", hipErrorLaunchFailure);
     return DET6D_ELAUNCH;
   }

@@ -305,20 +305,39 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   // software pipeline: the neighbour index of the tile after next and the point row of the next tile are in
   // flight while this tile computes (index -> row is a dependent pair of loads)
   struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; int oc[4]; };
-  auto fetch = [&](int t, int p) {   // t wave-uniform; for NS == 16 the two centres of a tile share the batch (m even)
-    TileIn in;
+  // list entries of a tile: neighbour index, and on compact lists the centre tag of the row and the tags of the pooled
+  // rows.  They are the FIRST of the gather's two dependent loads and travel a whole tile ahead of the rows / centres they
+  // address (round 2 fetched the tags together with the rows: every iteration then waited for an L2 round trip between
+  // the tag load and the centre load — the matrix pipe of this kernel was busy 39 % of the time on ray-cast scenes)
+  struct TileIdx { int p, cj; int oc[4]; };
+  auto fetch_idx = [&](int t) {
+    TileIdx ix;
+    ix.p = nb_idx[t * 32 + l31];
+    ix.cj = 0;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) ix.oc[qq] = -1;
     if (COMPACT) {
-      in.row = *reinterpret_cast<const float4 *>(g.a + (size_t)p * 4);
-      const int cj = g.crow_c[t * 32 + l31];
-      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
-      in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
-      in.cnt0 = in.cnt1 = 0;
+      ix.cj = g.crow_c[t * 32 + l31];
       const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int r = compact_out_row(sc, qq, kh);
-        in.oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
+        ix.oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
       }
+    }
+    return ix;
+  };
+  auto fetch = [&](int t, const TileIdx &ix) {   // t wave-uniform; for NS == 16 the two centres of a tile share the batch (m even)
+    TileIn in;
+    const int p = ix.p;
+    if (COMPACT) {
+      in.row = *reinterpret_cast<const float4 *>(g.a + (size_t)p * 4);
+      const int cj = ix.cj;
+      const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
+      in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
+      in.cnt0 = in.cnt1 = 0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) in.oc[qq] = ix.oc[qq];
       return in;
     }
     const int c0 = NS == 32 ? t : 2 * t;             // first centre of the tile (scalar)
@@ -331,8 +350,8 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     in.cnt1 = NS == 32 ? 0 : g.cnt[c0 + 1];
     return in;
   };
-  TileIn nxt = fetch(tile, nb_idx[tile * 32 + l31]);
-  int p_next = tile + n_waves < ntiles ? nb_idx[(tile + n_waves) * 32 + l31] : 0;
+  TileIn nxt = fetch(tile, fetch_idx(tile));
+  TileIdx ix_next = tile + n_waves < ntiles ? fetch_idx(tile + n_waves) : TileIdx{0, 0, {-1, -1, -1, -1}};
   // results are stored one iteration late, BEFORE the next prefetch is issued: the wait for the prefetched
   // inputs at the top of an iteration then never waits for this tile's stores (vmcnt counts in order)
   float pend[NT3][COMPACT ? 4 : 2];
@@ -358,8 +377,8 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     const TileIn cur = nxt;
     if (pend_tile >= 0) flush();
     if (tile + n_waves < ntiles) {
-      nxt = fetch(tile + n_waves, p_next);
-      if (tile + 2 * n_waves < ntiles) p_next = nb_idx[(tile + 2 * n_waves) * 32 + l31];
+      nxt = fetch(tile + n_waves, ix_next);
+      if (tile + 2 * n_waves < ntiles) ix_next = fetch_idx(tile + 2 * n_waves);
     }
     const float4 v0 = cur.row;
     const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
@@ -448,6 +467,38 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   flush();
 }
 
+// N k-steps of one 32 x 32 accumulator tile whose WEIGHT fragments come from LDS (w[u * stride], stride a compile-time
+// multiple of the row length) and whose activation fragments x[0..N) sit in registers.  The fragments of block b + 1 (8
+// k-steps) are requested BEFORE the MFMAs of block b and land in registers of their own: left to itself the compiler reads
+// every fragment (pair) into the same register right before its use and waits for the LDS round trip with one MFMA in
+// flight — the matrix pipe of mlp_chain_wide_kernel was busy 33-42 % of the time (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES,
+// profiles/r03_beam_*).  W_IS_A: the weights are the A operand (transposed layers) or the B operand (layer 3).
+template <int N, int STRIDE, bool W_IS_A>
+__device__ __forceinline__ void mfma_steps_lds(const float *__restrict__ w, const float *x, f32x16 &acc) {
+  constexpr int UB = 8, NB = (N + UB - 1) / UB;
+  float wb[2][UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u)
+    if (u < N) wb[0][u] = w[u * STRIDE];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if ((b + 1) * UB + u < N) wb[(b + 1) & 1][u] = w[((b + 1) * UB + u) * STRIDE];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (b * UB + u < N) {
+        if (W_IS_A) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[b & 1][u], x[b * UB + u], acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[b * UB + u], wb[b & 1][u], acc, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Wide register chain: the same transposed-accumulator scheme for the second SA layer's groups
 // ([68->64->64->128], [68->64->96->128]): 264 / 361 MFMAs per 32-row tile.  The weights (66-92 KB with the
@@ -509,36 +560,49 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   int tile = __builtin_amdgcn_readfirstlane(wave_global);
   if (tile >= ntiles) return;
 
-  float xin[S1];
+  float xin[S1 + 1];        // [S1] = the shift step's activation fragment (1 on the k0 half)
   float csub0, csub1;
   int cnt0, cnt1;
   int oc_n[4] = {-1, -1, -1, -1};
-  auto fetch = [&](int t) {   // t wave-uniform
+  // list entries of a tile (point row, centre tag, tags of the pooled rows): the FIRST of the gather's two dependent
+  // loads, requested a whole tile ahead of the rows they address (fetch_entries(t + 2 strides) while tile t computes)
+  int e_p = 0, e_c = 0, e_oc[4] = {-1, -1, -1, -1};
+  auto fetch_entries = [&](int t) {
     if (COMPACT) {
-      const int p = g.crow_p[t * 32 + l31];
+      e_p = g.crow_p[t * 32 + l31];
+      e_c = g.crow_c[t * 32 + l31];
+      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int r = compact_out_row(sc, qq, kh);
+        e_oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
+      }
+    } else {
+      e_p = g.idx[t * 32 + l31];
+    }
+  };
+  auto fetch = [&](int t) {   // t wave-uniform; consumes the entries fetch_entries(t) left in e_p / e_c / e_oc
+    if (COMPACT) {
+      const int p = e_p;
       const float *row = g.a + (size_t)p * K1;
       const float *src = row + 3 + kh;          // chain position j = 2s + kh reads column j + 3 (features) ...
 #pragma unroll
       for (int s = 0; s < S1 - 2; ++s) xin[s] = src[2 * s];
       xin[S1 - 2] = row[kh ? 0 : K1 - 1];       // ... then (pad, x) and (y, z): chain_col(64..67, 68) = 67, 0, 1, 2
       xin[S1 - 1] = row[kh ? 2 : 1];
-      const int cj = g.crow_c[t * 32 + l31];
+      const int cj = e_c;
       const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
       csub0 = kh ? c[0] : 0.f;
       csub1 = kh ? c[2] : c[1];
       cnt0 = cnt1 = 0;
-      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int r = compact_out_row(sc, qq, kh);
-        oc_n[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
-      }
+      for (int qq = 0; qq < 4; ++qq) oc_n[qq] = e_oc[qq];
       return;
     }
     const int c0 = NS == 32 ? t : 2 * t;
     const int bi = c0 / g.m;
     const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
-    const int p = g.idx[t * 32 + l31];
+    const int p = e_p;
     const float *row = g.a + ((size_t)bi * g.n + p) * K1;
     const float *src = row + 3 + kh;
 #pragma unroll
@@ -583,7 +647,9 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     }
   };
 
+  fetch_entries(tile);
   fetch(tile);
+  if (tile + n_waves < ntiles) fetch_entries(tile + n_waves);
   for (; tile < ntiles; tile += n_waves) {
     if (pend_tile >= 0) flush();
     const int my_cnt0 = cnt0, my_cnt1 = cnt1;
@@ -592,21 +658,24 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
     for (int qq = 0; qq < 4; ++qq) my_oc[qq] = oc_n[qq];
     xin[S1 - 2] = xin[S1 - 2] - csub0;     // pad | dx
     xin[S1 - 1] = xin[S1 - 1] - csub1;     // dy | dz
-    // ---- layer 1 (transposed): K1 -> C1 ----
-    float f1[S2];
+    xin[S1] = one_k0;
+    // ---- layer 1 (transposed): K1 -> C1, the shift as one more k-step (rows K1, K1 + 1 of the staged matrix) ----
+    float f1[S2 + 1];
 #pragma unroll
     for (int t = 0; t < T1; ++t) {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int s = 0; s < S1; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[(2 * s + kh) * C1 + 32 * t + l31], xin[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[(K1 + kh) * C1 + 32 * t + l31], one_k0, acc, 0, 0, 0);
+      mfma_steps_lds<S1 + 1, 2 * C1, true>(W1 + kh * C1 + 32 * t + l31, xin, acc);
       to_fragments(acc, f1 + 16 * t);
     }
-    // the input registers are free: start the next tile's gather now, it lands during layers 2 and 3
-    if (tile + n_waves < ntiles) fetch(tile + n_waves);
+    f1[S2] = one_k0;
+    // the input registers are free: start the next tile's gather now (its list entries arrived a tile ago), it lands
+    // during layers 2 and 3; then request the list entries of the tile after next
+    if (tile + n_waves < ntiles) {
+      fetch(tile + n_waves);
+      if (tile + 2 * n_waves < ntiles) fetch_entries(tile + 2 * n_waves);
+    }
     // ---- layer 2 (transposed): C1 -> C2 ----
     float f2[S3];
 #pragma unroll
@@ -614,10 +683,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int s = 0; s < S2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(2 * s + kh) * C2 + 32 * t + l31], f1[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(C1 + kh) * C2 + 32 * t + l31], one_k0, acc, 0, 0, 0);
+      mfma_steps_lds<S2 + 1, 2 * C2, true>(W2 + kh * C2 + 32 * t + l31, f1, acc);
       to_fragments(acc, f2 + 16 * t);
     }
     // ---- layer 3 (rows in the registers): C2 -> C3, pool, shift, ReLU, mask ----
@@ -626,9 +692,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       f32x16 o;
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[e] = 0.f;
-#pragma unroll
-      for (int s = 0; s < S3; ++s)
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[s], W3[(2 * s + kh) * C3 + 32 * j + l31], o, 0, 0, 0);
+      mfma_steps_lds<S3, 2 * C3, false>(W3 + kh * C3 + 32 * j + l31, f2, o);
       float q[4];
       if (COMPACT) {
 #pragma unroll

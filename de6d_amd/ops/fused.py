@@ -40,21 +40,75 @@ def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None, idx
     write into the concatenated index buffer all happen inside the kernel"""
     L.require_cuda(xyz, scores, idx_out)
     b, n_total, _ = xyz.shape
-    if temp is None:
+    own = temp is None
+    if own:
         temp = fps_workspace(b, hi - lo, xyz.device)
     L.call("det6d_fps_fused", b, n_total, lo, hi, m, L.ptr(xyz), L.ptr(scores), float(gamma), L.ptr(temp),
            temp.numel() * temp.element_size(), L.ptr(idx_out), idx_out.shape[1], idx_offset, idx_bias, L.stream_ptr())
+    if own and scores is None:
+        # a sampler that can fail after its launch (the cooperative one) on a workspace nobody else will look at: its error
+        # word goes to the capture controller (a captured pass copies it out after every replay) or, for eager calls, onto
+        # the list check_fps_status() drains (Detector3DTemplate.forward calls it where the pass synchronises anyway)
+        word = fps_status_word(b, hi - lo, temp)
+        if word is not None:
+            ctl = SAMPLER_SEGMENTS
+            if ctl is not None and hasattr(ctl, 'status_words'):
+                ctl.status_words.append(word)
+            elif not torch.cuda.is_current_stream_capturing():
+                PENDING_FPS_STATUS.append(word)
+                del PENDING_FPS_STATUS[:-64]
+
+
+#: error words (int32 device views) of eager cooperative sampler launches that nobody has checked yet
+PENDING_FPS_STATUS = []
+
+
+class FpsTimeout(L.Det6dError):
+    """a workgroup of the cooperative 32768 / 65536-point sampler gave up waiting for its partners: the picks of that
+    launch are placeholders (include/det6d_ops.h: det6d_fps_fused_status)"""
+
+
+def check_fps_status(words=None):
+    """raises FpsTimeout if a sampler launch behind one of `words` (default: the eager launches since the last call) gave up;
+    synchronises the current stream only when there is something to check.  A set word is cleared."""
+    pending = PENDING_FPS_STATUS if words is None else words
+    if not pending:
+        return
+    flags = torch.stack([w.reshape(()) for w in pending]).cpu()
+    bad = [w for w, f in zip(pending, flags.tolist()) if f]
+    if words is None:
+        del PENDING_FPS_STATUS[:]
+    for w in bad:
+        w.zero_()
+    if bad:
+        raise FpsTimeout("det6d_fps (cooperative): a workgroup waited ~2 s for its partners in %d launch(es); their picks "
+                         "are invalid" % len(bad))
 
 
 def fps_status(b, n, temp):
-    """raises if the last cooperative sampler launch on `temp` gave up (synchronises the current stream)"""
+    """raises if a cooperative sampler launch on `temp` gave up since the last check (synchronises the current stream)"""
     L.call("det6d_fps_fused_status", b, n, L.ptr(temp), temp.numel() * temp.element_size(), L.stream_ptr())
+
+
+def fps_status_word(b, n, temp):
+    """int32 view (1 element) of the sticky error word inside a sampler workspace, or None when the sampler that (b, n)
+    selects cannot fail after its launch (det6d_fps_fused_status_offset)"""
+    off = int(L.lib().det6d_fps_fused_status_offset(b, n, L.ptr(temp), temp.numel() * temp.element_size()))
+    if off < 0:
+        return None
+    return temp[off:off + 4].view(torch.int32)
+
+
+def fps_is_cooperative(n):
+    """does a d-fps launch over n points per scene use the cooperative multi-workgroup sampler?"""
+    return int(L.lib().det6d_fps_fused_workspace_bytes(1, n)) > 4 * n
 
 
 def fps_workspace(b, n, device='cuda'):
     """scratch of one sampler launch over b scenes of n points (det6d_fps_fused_workspace_bytes: (b, n) floats, more for
-    the cooperative sampler of 32768 / 65536-point scenes)"""
-    return torch.empty((int(L.lib().det6d_fps_fused_workspace_bytes(b, n)),), dtype=torch.uint8, device=device)
+    the cooperative sampler of 32768 / 65536-point scenes), zero-filled: the cooperative sampler's error word is sticky
+    and cleared only here and by a status read"""
+    return torch.zeros((int(L.lib().det6d_fps_fused_workspace_bytes(b, n)),), dtype=torch.uint8, device=device)
 
 
 def gather_centres(xyz, idx, rows_out=None, zero_from=0, out=None, idx_bias=0):
@@ -370,8 +424,8 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
     m = new_xyz.shape[1]
     dev = xyz.device
     if grid is None:
-        grid = GRID_QUERY_MIN_N <= n <= 98304
-    if grid:
+        grid = GRID_QUERY_MIN_N <= n
+    if grid and max(shell_a[2], shell_b[2]) <= 64:      # the grid kernel ranks one list entry per lane
         cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
         cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
         idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)

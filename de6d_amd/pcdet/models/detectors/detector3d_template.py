@@ -211,6 +211,13 @@ class Detector3DTemplate(nn.Module):
         return recall_dict
 
     # ------------------------------------------------------------------ checkpoints
+    def invalidate_folded(self):
+        """Call after editing parameters or BatchNorm statistics IN PLACE (param.data.copy_, an EMA swap, ...): the folded
+        Conv+BN matrices the HIP path multiplies with are cached per module and re-folded only by train() / eval() mode
+        CHANGES, load_state_dict-style loaders and this call; captured passes (runtime.GraphedDet6D) refuse to replay
+        across it (`weights_version`)."""
+        self._invalidate_folded()
+
     def _invalidate_folded(self):
         self.weights_version += 1
         for m in self.modules():

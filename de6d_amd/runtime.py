@@ -206,9 +206,11 @@ class _InlineHoist(object):
                 self.ctr[(step['layer'], step['j'])] = torch.empty((batch_size, step['m'], 3), dtype=torch.float32, device=dev)
         self._later = {(s['layer'], s['j']) for s in self.plan[1:]}
         self._layer = -1
+        self.status_words = []       # error words of samplers that can fail after their launch (fused.fps_fused appends)
 
     def reset(self):
         self._layer = -1
+        del self.status_words[:]
 
     def next_layer(self):
         self._layer += 1
@@ -316,6 +318,11 @@ class GraphedDet6D(object):
         self.count_host = torch.empty(self.count.shape, dtype=self.count.dtype, pin_memory=True)
         self.done = torch.cuda.Event()
         self._weights_version = getattr(model, 'weights_version', 0)
+        # samplers of this pass that can fail after their launch (the cooperative 32768 / 65536-point sampler): their
+        # sticky error words travel to pinned memory next to the counts and are looked at in finalize()
+        self._status_words = list(inline.status_words) if inline is not None else []
+        self._status_host = torch.zeros((max(1, len(self._status_words)),), dtype=torch.int32, pin_memory=True)
+        self._front_status = None     # (host int32 tensor, device words) of the Det6DGroup this pass belongs to
 
     def _relaunched(self):
         lazy = self.batch_dict.get('point_coords_list', None)
@@ -332,6 +339,8 @@ class GraphedDet6D(object):
         the pass's previous launch has finished with the buffers"""
         self._check_weights()
         self._relaunched()
+        if GraphedDet6D.stamp_launches:
+            self.issued_at = time.perf_counter()     # host time at which this launch of the pass was issued (bench.py)
         torch.cuda.current_stream().wait_event(self.done)
         if callable(points):          # an input producer filling self.points on the current stream (bench.py pipeline leg)
             points(self)
@@ -351,9 +360,32 @@ class GraphedDet6D(object):
             for graph in self.segments[1:]:
                 graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
+            self._copy_status()
             self.done.record()
             self._stamp()
         return self
+
+    def _copy_status(self):
+        for i, w in enumerate(self._status_words):
+            self._status_host[i:i + 1].copy_(w, non_blocking=True)
+
+    def _check_status(self):
+        """after `done`: did a sampler of this pass (or of its group's stage 1) give up?  (fps_coop.hip's time-out)"""
+        from .ops import fused
+        bad = []
+        if self._status_words and bool(self._status_host[:len(self._status_words)].any()):
+            bad += [w for w, f in zip(self._status_words, self._status_host.tolist()) if f]
+        if self._front_status is not None and bool(self._front_status[0].any()):
+            bad += [w for w, f in zip(self._front_status[1], self._front_status[0].tolist()) if f]
+        if bad:
+            for w in bad:
+                w.zero_()
+            torch.cuda.current_stream().synchronize()
+            self._status_host.zero_()
+            if self._front_status is not None:
+                self._front_status[0].zero_()
+            raise fused.FpsTimeout("a cooperative farthest-point sampler of this pass gave up waiting for its partner "
+                                   "workgroups (include/det6d_ops.h: det6d_fps_fused_status): the pass's detections are invalid")
 
     #: bench.py sets this to have every launch leave a timing event (`self.stamp`: device-side completion time of the pass)
     stamp_launches = False
@@ -366,6 +398,8 @@ class GraphedDet6D(object):
     def launch(self, points=None):
         self._check_weights()
         self._relaunched()
+        if GraphedDet6D.stamp_launches:
+            self.issued_at = time.perf_counter()
         with torch.cuda.stream(self.stream):
             if points is not None and points.data_ptr() != self.points.data_ptr():
                 self.points.copy_(points, non_blocking=True)
@@ -373,6 +407,7 @@ class GraphedDet6D(object):
                 raise RuntimeError("this pass belongs to a Det6DGroup: launch the group")
             self.graph.replay()
             self.count_host.copy_(self.count, non_blocking=True)
+            self._copy_status()
             self.done.record()
             self._stamp()
         return self
@@ -386,6 +421,7 @@ class GraphedDet6D(object):
             t0 = time.perf_counter()
             self.done.synchronize()
             GraphedDet6D.host_wait_s += time.perf_counter() - t0
+        self._check_status()
         return [{'pred_boxes': self.boxes[i, :k], 'pred_scores': self.scores[i, :k],
                  'pred_labels': self.labels[i, :k]} for i, k in enumerate(self.count_host.tolist())]
 
@@ -424,6 +460,9 @@ class Det6DGroup(object):
                 self.ctr_all[(layer, step['j'])] = torch.empty((nb, step['m'], 3), dtype=torch.float32, device=dev)
             self.ws[(layer, step['j'])] = fused.fps_workspace(nb, step['hi'] - step['lo'], dev)
         hoisted = {(s['layer'], s['j']) for s in self.plan}
+        self._status_words = [w for w in (fused.fps_status_word(nb, s['hi'] - s['lo'], self.ws[(s['layer'], s['j'])])
+                                          for s in self.plan) if w is not None]
+        self._status_host = torch.zeros((max(1, len(self._status_words)),), dtype=torch.int32, pin_memory=True)
         self.runners = []
         for j in range(k):
             sl = slice(j * batch_size, (j + 1) * batch_size)
@@ -432,6 +471,9 @@ class Det6DGroup(object):
                          hoisted=hoisted)
             self.runners.append(GraphedDet6D(model, batch_size, n_points, point_width, points=own, front=front,
                                              stream=None if main_streams is None else main_streams[j % len(main_streams)]))
+        if self._status_words:
+            for r in self.runners:
+                r._front_status = (self._status_host, self._status_words)
         self._fused = fused
         self._sampled = torch.cuda.Event()
         self._count = k
@@ -452,6 +494,8 @@ class Det6DGroup(object):
                 if step['feeds']:     # xyz of these picks: the cloud the next layer's hoisted sampler works on
                     F.gather_centres(src, idx[:nb, step['offset']:step['offset'] + step['m']], out=self.ctr_all[key][:nb],
                                      idx_bias=-step['bias'])
+            for i, w in enumerate(self._status_words):     # sticky error words -> pinned memory, looked at in finalize()
+                self._status_host[i:i + 1].copy_(w, non_blocking=True)
             self._sampled.record(self.hi)
         return self
 
@@ -463,6 +507,11 @@ class Det6DGroup(object):
 
     def launch(self, points=None, count=None):
         return self.launch_front(points, count).launch_rest()
+
+
+#: CUs the cooperative samplers in flight may occupy together (256 on MI355X, one 1024-thread workgroup each; margin for
+#: CUs whose LDS / registers other long-running workgroups hold)
+COOP_CUS = 224
 
 
 def warn_hw_queues(need):
@@ -511,6 +560,15 @@ class ScenePipeline(object):
         warn_hw_queues(n_main + sampler_streams)
         self.main_streams = list(main_streams) if main_streams else [torch.cuda.Stream() for _ in range(n_main)]
         self.sampler_streams = list(samplers) if samplers else [torch.cuda.Stream() for _ in range(sampler_streams)]
+        from .ops import fused
+        if fused.fps_is_cooperative(n_points):
+            # The cooperative sampler of 32768 / 65536-point scenes needs ALL parts of a scene resident at once (they
+            # poll each other).  Launches on different streams may be dispatched interleaved, so the launches in flight
+            # together must fit the chip with one 1024-thread workgroup per CU (COOP_CUS with a margin): stage 1 of the
+            # groups shares as few sampler streams as that allows (launches on one stream never overlap; inside one
+            # launch the parts of a scene are consecutive in dispatch order).
+            per_launch = min(group, n_main) * batch_size * (n_points // 16384)
+            self.sampler_streams = self.sampler_streams[:max(1, COOP_CUS // max(1, per_launch))]
         n_main = len(self.main_streams)
         self.n_groups = max(1, n_main // self.k) + prefetch
         self.groups = []

@@ -88,9 +88,10 @@ int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns
 
 /* Grid-hashed form of det6d_ball_query_pair for large N (identical results): a uniform (x, y) grid
  * with cell edge >= max(rout_a, rout_b) is built per scene, a centre tests only the points of its
- * 3x3 cell neighbourhood, hits are recorded in an N-bit LDS bitmap and read back in ascending index
- * order.  workspace: det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.
- * N <= 98304. */
+ * 3x3 cell neighbourhood and keeps, per shell, the nsample smallest hit indices (a short LDS list with a
+ * pruning threshold, ranked once at the end: the reference's ascending-index order).  workspace:
+ * det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.  ns_a, ns_b <= 64
+ * (DET6D_EINVAL beyond: use det6d_ball_query_pair). */
 int64_t det6d_ball_query_grid_workspace_bytes(int b, int n);
 int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
                                float rout_b, int ns_b, const float *new_xyz, const float *xyz,
@@ -278,10 +279,20 @@ int det6d_pack_points(int total, int cin, const float *points, int ld, float *ro
  * runs register-resident on 2 / 4 cooperating workgroups per scene (csrc/fps_coop.hip) instead of the
  * memory-resident kernel (same picks, ~100x faster). */
 long long det6d_fps_fused_workspace_bytes(int b, int n);
-/* After a det6d_fps_fused launch of b scenes of n = hi-lo points on `temp`: synchronises `stream` and returns DET6D_OK, or
- * DET6D_ELAUNCH when a workgroup of the cooperative sampler gave up waiting for its partners (the picks are then
- * invalid; it cannot happen unless the GPU refuses to co-schedule 4 workgroups for seconds).  Blocks: not capturable. */
+/* The cooperative sampler's failure path.  Its 2 / 4 workgroups per scene exchange candidates through memory; a workgroup
+ * that waits ~2 s for a partner that was never scheduled gives up, fills the rest of the scene's picks with the (valid)
+ * first index and sets an int32 error word inside the workspace.  The word is STICKY: `temp` must be zero-filled once when
+ * it is allocated, no launch clears the word, det6d_fps_fused_status clears it after reading it set.
+ * det6d_fps_fused_status: after launches of b scenes of n = hi-lo points on `temp`: synchronises `stream`; DET6D_OK, or
+ *   DET6D_ELAUNCH when a launch since the last read gave up (its picks are invalid).  Blocks: not capturable.
+ * det6d_fps_fused_status_offset: byte offset of that word from `temp` (so that a pipeline can copy it to pinned memory
+ *   next to its other results without a synchronisation of its own), -1 when the sampler that (b, n, temp_bytes) selects
+ *   cannot fail after its launch.
+ * Co-residency is the caller's to bound: cooperative launches in flight at the same time must not ask for more than one
+ * workgroup per CU in total (2 / 4 x scenes each), otherwise partially dispatched launches can starve each other until
+ * the time-out (de6d_amd/runtime.py: ScenePipeline keeps them on few enough streams). */
 int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream);
+long long det6d_fps_fused_status_offset(int b, int n, const float *temp, long long temp_bytes);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */

@@ -445,6 +445,30 @@ def test_ball_query_grid_adversarial(ext, oracle_ops):
             np.testing.assert_array_equal(ib.cpu().numpy(), oib)
 
 
+def test_ball_query_grid_dense_shells(ext, oracle_ops):
+    """shells with hundreds of hits per centre (the dense part of a real sweep): the running selection of the nsample
+    smallest hit indices is cut back several times per centre (csrc/ball_query_grid.hip: keep_smallest + threshold); point
+    order ascending, descending and shuffled inside the cells"""
+    fused = ext[2]
+    from tests.util import beam_batch
+    rng = np.random.default_rng(5)
+    n, m = 16384, 900
+    beam = beam_batch(4500, 1, n)[..., :3]
+    blob = (rng.normal(size=(1, n, 3)) * [2.0, 2.0, 0.3]).astype(np.float32)            # ~1000 points per 0.8 m cell
+    clouds = [beam, blob, np.ascontiguousarray(blob[:, ::-1]), np.ascontiguousarray(blob[:, np.argsort(blob[0, :, 0])])]
+    for xyz in clouds:
+        new_xyz = np.ascontiguousarray(xyz[:, rng.choice(n, m, replace=False)] + np.float32(0.003))
+        for sa, sb in [((0.0, 0.2, 16), (0.2, 0.8, 32)), ((0.0, 0.8, 16), (0.0, 0.8, 64))]:
+            oca, oia = oracle_ops.ball_query_dilated(sa[0], sa[1], sa[2], xyz, new_xyz)
+            ocb, oib = oracle_ops.ball_query_dilated(sb[0], sb[1], sb[2], xyz, new_xyz)
+            assert ocb.max() == sb[2]
+            ca, ia, cb, ib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb, grid=True)
+            np.testing.assert_array_equal(ca.cpu().numpy(), oca)
+            np.testing.assert_array_equal(ia.cpu().numpy(), oia)
+            np.testing.assert_array_equal(cb.cpu().numpy(), ocb)
+            np.testing.assert_array_equal(ib.cpu().numpy(), oib)
+
+
 @pytest.mark.parametrize("c_in,widths,ns", [(1, (16, 16, 32), 16), (1, (32, 32, 64), 32), (4, (24, 32, 40), 16), (1, (8, 16, 16), 32),
                                              (64, (64, 64, 128), 16), (64, (64, 96, 128), 32), (64, (64, 96, 128), 16), (64, (64, 64, 128), 32)])
 def test_mlp_chain3_equals_three_linears(ext, oracle_ops, c_in, widths, ns):

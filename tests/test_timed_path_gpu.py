@@ -270,3 +270,122 @@ def test_bench_entry_point_checks_itself():
     assert d['selfcheck'] == 'ok' and d['steps'] == 8 and d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['value'] > 0
     assert 'steady-state' in d['config']['timing'] and d['config']['points_per_scene'] == 16384
     assert d['config']['batches_per_pass'] == 4 and d['config']['scenes_per_pass'] == 32      # 8 steps = 2 coalesced passes
+
+
+def test_ray_cast_batch8_through_scene_pipeline_vs_oracle(oracle_ops):
+    """the `--scene beam` leg as bench.py times it: batch 8 x 16384 ray-cast scenes, coalesced 32-scene passes through
+    ScenePipeline (KITTI-like ball fill 0.3-0.9: the GEMM-bound regime), every step against the ORACLE's dense rows bit for
+    bit — the 64-row mlp_rows tiles, the 2048-workgroup chain grids and the full-ball class-32 tiles of the compact lists
+    only occur at these row counts"""
+    from de6d_amd.runtime import load_config, build_model, ScenePipeline
+    from tests.util import beam_batch
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=1234, device='cuda')
+    b, n, merge = 8, 16384, 4
+    batches_np = [flat_points(beam_batch(4300 + 20 * j, b, n)) for j in range(merge)]
+    batches = [torch.from_numpy(p).cuda() for p in batches_np]
+    inputs = ScenePipeline.coalesce(batches, merge)                      # one 32-scene pass input
+    pipe = ScenePipeline(model, b, n, n_main=4, group=1, prefetch=2, sampler_streams=2, points=inputs, merge=merge)
+    got = {}
+
+    def on_done(step, r, preds):
+        got[step] = [{k: v.clone() for k, v in p.items()} for p in preds]
+    assert pipe.run(2 * merge, on_done=on_done) == 2 * merge
+    torch.cuda.synchronize()
+    for j in range(merge):
+        ref = oracle_of(cfg, model, batches_np[j], b)
+        for step in (j, j + merge):                                     # every pass holds batches 0..3 in order
+            for g, w in zip(got[step], ref['pred_dicts']):
+                np.testing.assert_array_equal(g['pred_boxes'].cpu().numpy(), w['pred_boxes'])
+                np.testing.assert_array_equal(g['pred_scores'].cpu().numpy(), w['pred_scores'])
+                np.testing.assert_array_equal(g['pred_labels'].cpu().numpy(), w['pred_labels'])
+        assert sum(len(p['pred_scores']) for p in got[j]) > 0
+    # and the intermediate levels of one coalesced pass against the oracle run on all 32 scenes at once
+    r = pipe.passes[0]
+    r_pts = torch.cat(batches, 0).cpu().numpy()
+    r_pts[:, 0] = np.repeat(np.arange(b * merge, dtype=np.float32), n)
+    preds = r.finalize()
+    check(r.batch_dict, preds, oracle_of(cfg, model, r_pts, b * merge), b * merge)
+
+
+def test_cooperative_sampler_pipeline_under_load_reports_status(oracle_ops):
+    """65536-point scenes (BASELINE config 5) through ScenePipeline while 16 other streams keep the chip full of GEMM
+    workgroups: the cooperative sampler's parts must all get scheduled (ScenePipeline bounds the cooperative launches in
+    flight), its sticky error word stays 0 (finalize() would raise FpsTimeout), results equal the eager model"""
+    from de6d_amd.ops import fused
+    from de6d_amd.runtime import load_config, build_model, ScenePipeline
+    cfg = load_config('synthetic_models/det6d_65536.yaml')
+    model = build_model(cfg, seed=77, device='cuda')
+    b, n = 2, 65536
+    assert fused.fps_is_cooperative(n) and not fused.fps_is_cooperative(16384)
+    batches = [torch.from_numpy(flat_points(make_batch(8300 + 10 * j, b, n))).cuda() for j in range(2)]
+    with torch.no_grad():
+        eager = [model({'batch_size': b, 'points': p})[0] for p in batches]
+    torch.cuda.synchronize()
+    pipe = ScenePipeline(model, b, n, n_main=4, group=1, prefetch=2, sampler_streams=6, points=batches)
+    assert len(pipe.sampler_streams) <= 224 // (b * 4)       # bounded: 8 cooperative workgroups per launch here
+    assert all(g._status_words for g in pipe.groups)          # every group watches its sampler's error word
+    # background load: 16 streams of large GEMMs for the whole run
+    x = torch.randn((8192, 1024), device='cuda')
+    w = torch.randn((1024, 1024), device='cuda')
+    load_streams = [torch.cuda.Stream() for _ in range(16)]
+    stop = torch.zeros((), dtype=torch.int32)
+
+    def load(k):
+        for s in load_streams:
+            with torch.cuda.stream(s):
+                for _ in range(k):
+                    torch.mm(x, w)
+    which = {id(r): i % len(batches) for i, r in enumerate(pipe.passes)}
+    seen = []
+
+    def on_done(step, r, preds):
+        for g, e in zip(preds, eager[which[id(r)]]):
+            assert torch.equal(g['pred_boxes'], e['pred_boxes']) and torch.equal(g['pred_scores'], e['pred_scores'])
+        seen.append(step)
+        load(4)
+    load(40)
+    assert pipe.run(24, on_done=on_done) == 24 and seen == list(range(24))
+    torch.cuda.synchronize()
+    for g in pipe.groups:
+        assert int(torch.stack([w_.reshape(()) for w_ in g._status_words]).sum()) == 0
+    del stop
+
+
+def test_sampler_failure_is_raised_by_finalize():
+    """the host side of the cooperative sampler's failure path: a set error word (here set by hand: the device sets it after
+    ~2 s without its partners) reaches finalize() through the pinned copy and raises FpsTimeout once; the word is cleared"""
+    from de6d_amd.ops import fused
+    from de6d_amd.runtime import load_config, build_model, Det6DGroup, GraphedDet6D
+    cfg = load_config('synthetic_models/det6d_65536.yaml')
+    model = build_model(cfg, seed=77, device='cuda')
+    b, n = 1, 65536
+    pts = torch.from_numpy(flat_points(make_batch(8400, b, n))).cuda()
+    group = Det6DGroup(model, b, n, 1, torch.cuda.Stream(), points=[pts], main_streams=[torch.cuda.Stream()])
+    group.launch()[0].finalize()                                   # a clean run
+    group._status_words[0].fill_(1)
+    torch.cuda.synchronize()
+    r = group.launch()[0]
+    with pytest.raises(fused.FpsTimeout):
+        r.finalize()
+    torch.cuda.synchronize()
+    assert int(group._status_words[0]) == 0
+    group.launch()[0].finalize()                                   # cleared: the next pass is fine again
+    # single-graph pass: the word of the sampler captured inside the graph
+    runner = GraphedDet6D(model, b, n)
+    assert runner._status_words
+    runner.launch(pts).finalize()
+    # eager: Det6D.forward checks the launches it made
+    with torch.no_grad():
+        model({'batch_size': b, 'points': pts})
+    assert not fused.PENDING_FPS_STATUS
+    # C entry: sticky word read and cleared by det6d_fps_fused_status
+    ws = fused.fps_workspace(b, n)
+    word = fused.fps_status_word(b, n, ws)
+    fused.fps_status(b, n, ws)
+    word.fill_(1)
+    from de6d_amd._lib import Det6dError
+    with pytest.raises(Det6dError):
+        fused.fps_status(b, n, ws)
+    torch.cuda.synchronize()
+    assert int(word) == 0
