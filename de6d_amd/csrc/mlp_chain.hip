@@ -68,15 +68,25 @@ __device__ __forceinline__ void compact_store(float *dst, float val, int tag) {
   if (tag & 0x20000000) __hip_atomic_fetch_max(reinterpret_cast<int *>(dst), __builtin_bit_cast(int, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *dst = val;
 }
-// classes 1 and 2: every accumulator (pair) of a 32x32 tile is a group of its own: stored at once (no pending slot)
-__device__ __forceinline__ void compact_store_small(const ChainArgs &g, const f32x16 &o, int s, int tile, int kh, int col, float sh) {
+// classes 1 and 2: every accumulator (pair) of a 32x32 tile is a group of its own: stored at once (no pending slot).
+// tags[e] = centre tag of the row accumulator e of this lane holds (compact_row_tags).
+__device__ __forceinline__ void compact_store_small(const ChainArgs &g, const f32x16 &o, int s, const int (&tags)[16], int col, float sh) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     if (s == 2 && (e & 1)) continue;
     const float raw = s == 2 ? d6_vmax(o[e], o[e + 1 < 16 ? e + 1 : e]) : o[e];
-    const int tag = g.crow_c[tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+    const int tag = tags[e];
     if (tag >= 0) compact_store(g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + col, (tag & 0x40000000) ? 0.f : d6_relu(raw + sh), tag);
   }
+}
+// Row tags of a tile from the lanes that loaded them (lane r and r + 32 hold the tag of row r): accumulator e of a lane in
+// half kh is row (e & 3) + 8 (e >> 2) + 4 kh.  A cross-lane read (ds_bpermute, no memory) instead of a global load per
+// accumulator: round 2 re-read crow_c inside the epilogue, 16 dependent L2 round trips per column tile, and — the class
+// regions being contiguous — the workgroups that owned the tail of the list (classes 2 and 1) ran several times longer
+// than the others (the kernels' matrix pipes were busy 33-42 %: profiles/r03_beam_*).
+__device__ __forceinline__ void compact_row_tags(int my_tag, int kh, int (&tags)[16]) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) tags[e] = __shfl(my_tag, (e & 3) + 8 * (e >> 2) + 4 * kh);
 }
 // the four 4-row maxima of a lane -> pooled values of class s (in place; v[qq] valid where compact_out_row >= 0)
 __device__ __forceinline__ void compact_pool(float (&v)[4], int s) {
@@ -267,15 +277,16 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int n_waves = (gridDim.x * blockDim.x) >> 6;
   int pk_end = 0;
-  if (COMPACT) {   // tiles of a compact list packed onto few waves (>= kPackTiles each): fewer weight-fragment loads, fewer CUs held
+  if (COMPACT) {
+    // the live tiles of a compact list go round the workgroups that are needed (one tile per wave at least): tile t -> wave
+    // t mod (active waves).  The class regions are contiguous (32-row parts first, single rows last) and the small classes
+    // have the dearest epilogue, so contiguous chunks per workgroup (round 2) left the tail of the list to a few workgroups.
     const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32;
-    int T = (live + n_waves - 1) / n_waves;
-    if (T < kPackTiles) T = kPackTiles;
-    const int base = blockIdx.x * wpw * T;
-    if (base >= live) return;
-    wave_global = base + (threadIdx.x >> 6);
-    n_waves = wpw;
-    pk_end = base + wpw * T < live ? base + wpw * T : live;
+    int nb = (live + wpw * kPackTiles - 1) / (wpw * kPackTiles);
+    if (nb > (int)gridDim.x) nb = gridDim.x;
+    if ((int)blockIdx.x >= nb) return;
+    n_waves = nb * wpw;
+    pk_end = live;
   }
 
   // weight fragments: lane (channel / column = l31, k = 2s + kh); one more step per transposed layer for the shift
@@ -304,27 +315,16 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
   if (tile >= ntiles) return;
   // software pipeline: the neighbour index of the tile after next and the point row of the next tile are in
   // flight while this tile computes (index -> row is a dependent pair of loads)
-  struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; int oc[4]; };
+  struct TileIn { float4 row; float cx, cy, cz; int cnt0, cnt1; int oc[4]; int tag; };
   // list entries of a tile: neighbour index, and on compact lists the centre tag of the row and the tags of the pooled
   // rows.  They are the FIRST of the gather's two dependent loads and travel a whole tile ahead of the rows / centres they
   // address (round 2 fetched the tags together with the rows: every iteration then waited for an L2 round trip between
   // the tag load and the centre load — the matrix pipe of this kernel was busy 39 % of the time on ray-cast scenes)
-  struct TileIdx { int p, cj; int oc[4]; };
+  struct TileIdx { int p, cj; };
   auto fetch_idx = [&](int t) {
     TileIdx ix;
     ix.p = nb_idx[t * 32 + l31];
-    ix.cj = 0;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) ix.oc[qq] = -1;
-    if (COMPACT) {
-      ix.cj = g.crow_c[t * 32 + l31];
-      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int r = compact_out_row(sc, qq, kh);
-        ix.oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
-      }
-    }
+    ix.cj = COMPACT ? g.crow_c[t * 32 + l31] : 0;
     return ix;
   };
   auto fetch = [&](int t, const TileIdx &ix) {   // t wave-uniform; for NS == 16 the two centres of a tile share the batch (m even)
@@ -336,10 +336,18 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
       const float *c = g.ctr + (size_t)(cj < 0 ? 0 : cj & 0x1fffffff) * g.ldctr;
       in.cx = c[0]; in.cy = c[1]; in.cz = c[2];
       in.cnt0 = in.cnt1 = 0;
+      in.tag = cj;
+      // tags of the rows whose centres own this lane's pooled values: held by lane `row` (no second load of the list)
+      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) in.oc[qq] = ix.oc[qq];
+      for (int qq = 0; qq < 4; ++qq) {
+        const int r = compact_out_row(sc, qq, kh);
+        const int tg = __shfl(cj, r < 0 ? 0 : r);
+        in.oc[qq] = r >= 0 ? tg : -1;
+      }
       return in;
     }
+    in.tag = 0;
     const int c0 = NS == 32 ? t : 2 * t;             // first centre of the tile (scalar)
     const int bi = c0 / g.m;                         // scalar division
     const int cj = NS == 32 ? c0 : c0 + (l31 >> 4);
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
     return in;
   };
   TileIn nxt = fetch(tile, fetch_idx(tile));
-  TileIdx ix_next = tile + n_waves < ntiles ? fetch_idx(tile + n_waves) : TileIdx{0, 0, {-1, -1, -1, -1}};
+  TileIdx ix_next = tile + n_waves < ntiles ? fetch_idx(tile + n_waves) : TileIdx{0, 0};
   // results are stored one iteration late, BEFORE the next prefetch is issued: the wait for the prefetched
   // inputs at the top of an iteration then never waits for this tile's stores (vmcnt counts in order)
   float pend[NT3][COMPACT ? 4 : 2];
@@ -433,7 +441,9 @@ __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
         for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
         const int sc = compact_class(tile * 32, h1, h2, h3, h4, h5);
         if (sc < 4) {
-          compact_store_small(g, o, sc, tile, kh, col, sh3[j]);
+          int tags[16];
+          compact_row_tags(cur.tag, kh, tags);
+          compact_store_small(g, o, sc, tags, col, sh3[j]);
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) pend[j][qq] = 0.f;
           continue;
@@ -522,15 +532,14 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   // workgroups — at least kPackTiles tiles per wave, workgroup w owns tiles [w * 8T, (w + 1) * 8T) — so that the 66-92 KB
   // of weights are staged by ~35 workgroups instead of 256 (SA2, batch 8); the others leave before staging.
   int pk_stride = 0, pk_first = 0, pk_end = 0;
-  if (COMPACT) {
-    const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32, waves = gridDim.x * wpw;
-    int T = (live + waves - 1) / waves;
-    if (T < kPackTiles) T = kPackTiles;
-    const int base = blockIdx.x * wpw * T;
-    if (base >= live) return;
-    pk_stride = wpw;
-    pk_first = base + (tid >> 6);
-    pk_end = base + wpw * T < live ? base + wpw * T : live;
+  if (COMPACT) {   // tile t -> wave t mod (active waves): every workgroup sees the same mix of classes (see mlp_chain_reg_kernel)
+    const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32;
+    int nb = (live + wpw * kPackTiles - 1) / (wpw * kPackTiles);
+    if (nb > (int)gridDim.x) nb = gridDim.x;
+    if ((int)blockIdx.x >= nb) return;
+    pk_stride = nb * wpw;
+    pk_first = blockIdx.x * wpw + (tid >> 6);
+    pk_end = live;
   }
   // staging with 16-byte loads (all leading dimensions and widths are multiples of 4)
   auto stage = [&](float *dst, const float *w, int ldw, const float *shift, int k_rows, int cols, bool chain_order) {
@@ -566,17 +575,11 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   int oc_n[4] = {-1, -1, -1, -1};
   // list entries of a tile (point row, centre tag, tags of the pooled rows): the FIRST of the gather's two dependent
   // loads, requested a whole tile ahead of the rows they address (fetch_entries(t + 2 strides) while tile t computes)
-  int e_p = 0, e_c = 0, e_oc[4] = {-1, -1, -1, -1};
+  int e_p = 0, e_c = 0, tag_n = 0;
   auto fetch_entries = [&](int t) {
     if (COMPACT) {
       e_p = g.crow_p[t * 32 + l31];
       e_c = g.crow_c[t * 32 + l31];
-      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int r = compact_out_row(sc, qq, kh);
-        e_oc[qq] = r >= 0 ? g.crow_c[t * 32 + r] : -1;
-      }
     } else {
       e_p = g.idx[t * 32 + l31];
     }
@@ -595,8 +598,14 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       csub0 = kh ? c[0] : 0.f;
       csub1 = kh ? c[2] : c[1];
       cnt0 = cnt1 = 0;
+      tag_n = cj;
+      const int sc = compact_class(t * 32, h1, h2, h3, h4, h5);
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) oc_n[qq] = e_oc[qq];
+      for (int qq = 0; qq < 4; ++qq) {   // tags of the pooled rows from the lanes that hold them
+        const int r = compact_out_row(sc, qq, kh);
+        const int tg = __shfl(cj, r < 0 ? 0 : r);
+        oc_n[qq] = r >= 0 ? tg : -1;
+      }
       return;
     }
     const int c0 = NS == 32 ? t : 2 * t;
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   if (tile + n_waves < ntiles) fetch_entries(tile + n_waves);
   for (; tile < ntiles; tile += n_waves) {
     if (pend_tile >= 0) flush();
-    const int my_cnt0 = cnt0, my_cnt1 = cnt1;
+    const int my_cnt0 = cnt0, my_cnt1 = cnt1, my_tag = tag_n;
     int my_oc[4];
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) my_oc[qq] = oc_n[qq];
@@ -699,7 +708,9 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
         for (int qq = 0; qq < 4; ++qq) q[qq] = d6_vmax(d6_vmax(o[4 * qq], o[4 * qq + 1]), d6_vmax(o[4 * qq + 2], o[4 * qq + 3]));
         const int sc = compact_class(tile * 32, h1, h2, h3, h4, h5);
         if (sc < 4) {
-          compact_store_small(g, o, sc, tile, kh, 32 * j + l31, sh3[j]);
+          int tags[16];
+          compact_row_tags(my_tag, kh, tags);
+          compact_store_small(g, o, sc, tags, 32 * j + l31, sh3[j]);
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) pend[j][qq] = 0.f;
           continue;
