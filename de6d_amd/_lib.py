@@ -114,7 +114,7 @@ _SIGNATURES = {
 #: every symbol include/det6d_ops.h declares (tests/test_boundary.py checks the export table)
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
                                                   "det6d_postprocess_workspace_bytes", "det6d_fps_fused_workspace_bytes",
-                                                  "det6d_fps_fused_status_offset",
+                                                  "det6d_fps_fused_status_offset", "det6d_mlp_rows_supported",
                                                   "det6d_ball_query_grid_workspace_bytes",
                                                   "det6d_prepare_points_workspace_bytes",
                                                   "det6d_compact_rows_capacity", "det6d_compact_hdr_ints"])
@@ -145,6 +145,8 @@ def lib():
         handle.det6d_prepare_points_workspace_bytes.restype = c_int64
         handle.det6d_fps_fused_workspace_bytes.argtypes = [c_int, c_int]
         handle.det6d_fps_fused_workspace_bytes.restype = c_int64
+        handle.det6d_mlp_rows_supported.argtypes = [c_int, _P, _P]
+        handle.det6d_mlp_rows_supported.restype = c_int
         handle.det6d_fps_fused_status_offset.argtypes = [c_int, c_int, _P, c_int64]
         handle.det6d_fps_fused_status_offset.restype = c_int64
         handle.det6d_compact_hdr_ints.argtypes = [c_int]

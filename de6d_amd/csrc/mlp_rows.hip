@@ -201,11 +201,10 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
 
 }  // namespace
 
-DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
-                             const det6d_rows_layer *layers, det6d_stream_t stream) {
-  if (rows < 0 || !x || ldx <= 0 || xcol0 < 0 || nchains < 1 || nchains > 2 || !nlayers || !layers) return DET6D_EINVAL;
-  RowsArgs g;
-  g.rows = rows; g.x = x; g.ldx = ldx; g.xcol0 = xcol0;
+// Validates a stack description and derives the LDS plan: k0 (input width), wa / wb (row widths of the two activation
+// buffers), kchunk (columns of the input held in LDS at a time).  Shared by det6d_mlp_rows and det6d_mlp_rows_supported.
+static int rows_plan(int nchains, const int *nlayers, const det6d_rows_layer *layers, RowsArgs &g) {
+  if (nchains < 1 || nchains > 2 || !nlayers || !layers) return DET6D_EINVAL;
   int wa = 0, wb = 0, k0 = -1, off = 0;
   for (int c = 0; c < 2; ++c) g.nlayers[c] = 0;
   for (int c = 0; c < nchains; ++c) {
@@ -232,7 +231,6 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
     }
     off += nl;
   }
-  if (xcol0 + k0 > ldx) return DET6D_EINVAL;
   g.k0 = k0; g.wa = wa; g.wb = wb > 0 ? wb : 1;
   g.kchunk = k0;
   if (k0 >= 512 && (k0 % 256) == 0) {      // a wide input whose first layers have at most four column tiles: K-chunks of 256
@@ -245,6 +243,26 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
     }
     if (narrow) { g.kchunk = 256; g.wa = wa_rest; }
   }
+  // one 32-row tile's two activation buffers must fit the CU's 160 KB (64-row tiles are chosen only for narrow stacks)
+  if (sizeof(float) * 32 * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1)) > 160 * 1024) return DET6D_EINVAL;
+  return DET6D_OK;
+}
+
+// 1 when det6d_mlp_rows accepts this stack (widths, chain structure, LDS), else 0: the host asks BEFORE it routes a stack of
+// plain layers here instead of through one det6d_linear per layer (e.g. a [1024 -> 1024 -> ..] tower does not fit).
+DET6D_API int det6d_mlp_rows_supported(int nchains, const int *nlayers, const det6d_rows_layer *layers) {
+  RowsArgs g;
+  return rows_plan(nchains, nlayers, layers, g) == DET6D_OK ? 1 : 0;
+}
+
+DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
+                             const det6d_rows_layer *layers, det6d_stream_t stream) {
+  if (rows < 0 || !x || ldx <= 0 || xcol0 < 0) return DET6D_EINVAL;
+  RowsArgs g;
+  if (rows_plan(nchains, nlayers, layers, g) != DET6D_OK) return DET6D_EINVAL;
+  g.rows = rows; g.x = x; g.ldx = ldx; g.xcol0 = xcol0;
+  const int k0 = g.k0;
+  if (xcol0 + k0 > ldx) return DET6D_EINVAL;
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
   // narrow stacks (every layer at most two column tiles, single chain, many rows): 64-row tiles

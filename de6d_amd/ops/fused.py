@@ -312,20 +312,28 @@ def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, c
 ROWS_KERNEL = os.environ.get('DET6D_NO_ROWS_KERNEL') is None
 
 
+def _rows_descriptors(chains, ptr_of=None):
+    flat = [l for chain in chains for l in chain]
+    arr = (L.RowsLayer * len(flat))()
+    for d, (w, wrow0, shift, k, n, act, out, ocol0) in zip(arr, flat):
+        d.w, d.ldw, d.wrow0 = w.data_ptr(), w.shape[1], wrow0
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.k, d.n, d.act = k, n, act
+        if out is not None:
+            d.out, d.ldo, d.ocol0 = (out.data_ptr() if ptr_of is None else ptr_of(out)), out.shape[-1], ocol0
+    return flat, (ctypes.c_int * len(chains))(*[len(c) for c in chains]), arr
+
+
 def mlp_rows_eligible(k0, chains):
-    """chains: [[(w, wrow0, shift, k, n, act, out, ocol0), ...], ...]"""
-    if not ROWS_KERNEL or not 1 <= len(chains) <= 2 or k0 % 32 or k0 > 1024:
+    """chains: [[(w, wrow0, shift, k, n, act, out, ocol0), ...], ...]; the library decides (det6d_mlp_rows_supported: chain
+    structure, widths and the LDS a tile's activation buffers take), so a stack that does not fit goes through run_chain's
+    one-launch-per-layer route instead of failing inside the forward pass or a graph capture"""
+    if not ROWS_KERNEL or not 1 <= len(chains) <= 2 or not all(1 <= len(c) <= 4 and c[0][3] == k0 for c in chains):
         return False
-    for chain in chains:
-        if not 1 <= len(chain) <= 4 or chain[0][3] != k0:
-            return False
-        kin = k0
-        for li, (w, wrow0, shift, k, n, act, out, ocol0) in enumerate(chain):
-            last = li == len(chain) - 1
-            if k != kin or k % 32 or k > 1024 or (not last and n % 32) or (last and out is None) or act not in (0, 1):
-                return False
-            kin = n
-    return True
+    if any(l[5] not in (0, 1) for c in chains for l in c):
+        return False
+    _, counts, arr = _rows_descriptors(chains)
+    return bool(L.lib().det6d_mlp_rows_supported(len(chains), counts, arr))
 
 
 def mlp_rows(x, xcol0, chains):
@@ -333,16 +341,9 @@ def mlp_rows(x, xcol0, chains):
     L.require_cuda(x)
     rows = x.numel() // x.shape[-1]
     flat = [l for chain in chains for l in chain]
-    counts = (ctypes.c_int * len(chains))(*[len(c) for c in chains])
 
     def issue(ptr_of=None):
-        arr = (L.RowsLayer * len(flat))()
-        for d, (w, wrow0, shift, k, n, act, out, ocol0) in zip(arr, flat):
-            d.w, d.ldw, d.wrow0 = w.data_ptr(), w.shape[1], wrow0
-            d.shift = shift.data_ptr() if shift is not None else None
-            d.k, d.n, d.act = k, n, act
-            if out is not None:
-                d.out, d.ldo, d.ocol0 = (out.data_ptr() if ptr_of is None else ptr_of(out)), out.shape[-1], ocol0
+        _, counts, arr = _rows_descriptors(chains, ptr_of)
         L.call("det6d_mlp_rows", rows, L.ptr(x) if ptr_of is None else ctypes.c_void_p(ptr_of(x)), x.shape[-1], xcol0, len(chains),
                counts, arr, L.stream_ptr())
     ev = None

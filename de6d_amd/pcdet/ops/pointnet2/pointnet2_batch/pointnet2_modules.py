@@ -191,9 +191,17 @@ class _PointnetSAModuleFSBase(nn.Module):
         (also under hipGraph capture, where the fork/join becomes two parallel branches)."""
         jobs = list(zip(self.sample_range_list, self.sample_method_list, self.npoint_list))
         b = xyz.shape[0]
-        ctl = fused.SAMPLER_SEGMENTS if (len(jobs) == 1 or SEQUENTIAL_SAMPLERS) else None   # segmented graph capture (runtime.py)
+        ctl = fused.SAMPLER_SEGMENTS                                  # capture controller of a pass (runtime.py), or None
+        # the controller counts EVERY layer (its index buffers and hoisted samplers are keyed by layer number) ...
         layer = ctl.next_layer() if ctl is not None else -1
+        if ctl is not None and not (len(jobs) == 1 or SEQUENTIAL_SAMPLERS):
+            # ... but it cannot serve a layer whose samplers run on forked streams (DET6D_FORKED_SAMPLERS=1): its hoisted
+            # picks would be recomputed into a private buffer and the group's buffers ignored
+            raise RuntimeError("DET6D_FORKED_SAMPLERS=1 cannot be combined with captured passes (GraphedDet6D / Det6DGroup "
+                               "hoist the input-only samplers): unset it, or run the model eagerly")
         idx = ctl.index_buffer(layer, b, sum(self.npoint_list)) if ctl is not None else None
+        if idx is not None:
+            assert tuple(idx.shape) == (b, sum(self.npoint_list)), "index buffer of layer %d has the wrong shape" % layer
         if idx is None:
             idx = torch.empty((b, sum(self.npoint_list)), dtype=torch.int32, device=xyz.device)
         offsets = [sum(self.npoint_list[:i]) for i in range(len(jobs))]

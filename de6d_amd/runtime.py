@@ -270,7 +270,11 @@ class GraphedDet6D(object):
             raise NotImplementedError('graph capture needs the fused class-agnostic nms_gpu post-processing')
 
         inline = None
-        if front is None and os.environ.get('DET6D_NO_HOIST') is None:
+        forked = os.environ.get('DET6D_FORKED_SAMPLERS') is not None      # the samplers of a layer on forked streams
+        if forked and front is not None:
+            raise RuntimeError("DET6D_FORKED_SAMPLERS=1 cannot be combined with a Det6DGroup (its passes take the hoisted "
+                               "samplers' picks from the group's buffers)")
+        if front is None and os.environ.get('DET6D_NO_HOIST') is None and not forked:
             inline = _InlineHoist(model, batch_size, n_points)
 
         def body():

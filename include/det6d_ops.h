@@ -312,6 +312,9 @@ typedef struct det6d_rows_layer {
 } det6d_rows_layer;
 int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
                    const det6d_rows_layer *layers, det6d_stream_t stream);
+/* 1 when det6d_mlp_rows accepts this stack (same checks, incl. the 160 KB of LDS a 32-row tile's two activation buffers
+ * may take), else 0 — asked by the host before it routes a stack here instead of through one det6d_linear per layer. */
+int det6d_mlp_rows_supported(int nchains, const int *nlayers, const det6d_rows_layer *layers);
 
 /* A wide three-layer grouped MLP in ONE launch (csrc/mlp_group.hip): layer 1 from the per-point partial sums exactly as
  * det6d_group_expand, layers 2 and 3 as fp32 MFMA GEMMs on 32-row tiles whose activations stay in LDS (weights streamed

@@ -221,3 +221,22 @@ def test_bench_coalesce_factor():
     assert bench.coalesce_factor(8, 7) == 1 and bench.coalesce_factor(8, 6) == 3
     assert bench.coalesce_factor(4, 20) == 5 and bench.coalesce_factor(4, 192) == 8
     assert bench.coalesce_factor(32, 20) == 1 and bench.coalesce_factor(64, 20) == 1
+
+
+def test_mlp_rows_supported_query_mirrors_the_launch_checks():
+    """det6d_mlp_rows_supported (host logic of csrc/mlp_rows.hip: chain structure, widths, the 160 KB of LDS a 32-row tile's
+    two activation buffers may take) decides fused.mlp_rows_eligible: a stack that does not fit is routed through one
+    det6d_linear per layer instead of failing inside the forward pass"""
+    import torch
+    from de6d_amd.ops import fused
+    z = lambda *s: torch.zeros(s)   # noqa: E731
+    out = z(4, 1024)
+    ok = [[(z(256, 128), 0, None, 256, 128, 1, None, 0), (z(128, 64), 0, None, 128, 64, 1, None, 0), (z(64, 4), 0, None, 64, 1, 0, z(4, 4), 0)]]
+    assert fused.mlp_rows_eligible(256, ok)
+    towers = [[(z(512, 128), 0, None, 512, 128, 1, None, 0), (z(128, 4), 0, None, 128, 1, 0, z(4, 4), 0)],
+              [(z(512, 128), 0, None, 512, 128, 1, None, 0), (z(128, 32), 0, None, 128, 32, 0, z(4, 32), 0)]]
+    assert fused.mlp_rows_eligible(512, towers)                       # K-chunked wide input
+    assert not fused.mlp_rows_eligible(1024, [[(z(1024, 1024), 0, None, 1024, 1024, 1, None, 0), (z(1024, 1024), 0, None, 1024, 1024, 1, out, 0)]])
+    assert not fused.mlp_rows_eligible(96, [[(z(96, 50), 0, None, 96, 50, 1, None, 0), (z(50, 4), 0, None, 50, 1, 0, z(4, 4), 0)]])   # hidden width % 32
+    assert not fused.mlp_rows_eligible(256, [[(z(256, 128), 0, None, 256, 128, 1, None, 0)]])    # last layer without an output
+    assert not fused.mlp_rows_eligible(256, ok + ok + ok)                                           # three chains

@@ -196,6 +196,25 @@ for i in range(0, len(mine), b):
     for s, p in list(zip(ids, preds))[:len(mine[i:i + b])]:
         results.append({'scene': s, 'boxes': p['pred_boxes'].cpu().numpy(), 'scores': p['pred_scores'].cpu().numpy()})
 merged = parallel.gather_detections(results, num_scenes)
+# the optional training-side collective (north star: "RCCL all-reduce over xGMI wired only for the optional training grad
+# step"): the model's whole gradient as ONE flat bucket, one all-reduce.  Under RCCL when every rank has a device of its
+# own; on a one-GPU box the bucket is reduced over gloo from host copies of the same gradients.
+params = [p for p in model.parameters()]
+for i, p in enumerate(params):
+    p.grad = torch.full_like(p, float(rank + 1) * (1.0 + (i % 7)))
+if ndev >= world:
+    nred = parallel.allreduce_gradients(params)
+    got = [p.grad for p in params]
+else:
+    host = [torch.nn.Parameter(p.detach().cpu()) for p in params]
+    for h, p in zip(host, params):
+        h.grad = p.grad.cpu()
+    nred = parallel.allreduce_gradients(host)
+    got = [h.grad for h in host]
+assert nred == sum(p.numel() for p in params)
+mean_rank = (world + 1) / 2.0
+for i, g in enumerate(got):
+    assert torch.all(g == mean_rank * (1.0 + (i % 7))), i
 if rank == 0:
     np.savez(os.environ['DET6D_OUT'], order=np.array([m['scene'] for m in merged]),
              **{'boxes_%d' % m['scene']: m['boxes'] for m in merged}, **{'scores_%d' % m['scene']: m['scores'] for m in merged})
