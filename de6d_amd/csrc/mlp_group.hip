@@ -38,6 +38,7 @@ struct GroupArgs {
   const int *hdr; const int *crow_p; const int *crow_c;   // compact rows
   float *y; int ldy; int col0;
   int pre;                                        // A/B switch: list entries of the next tile requested a K loop ahead
+  int yvec;                                       // y rows are 16-byte aligned (ldy, col0 multiples of 4): vector stores allowed
 };
 
 // ---- compact-row helpers (same conventions as mlp_chain.hip / linear.hip; see compact.hip for the list layout) ----
@@ -81,6 +82,53 @@ template <int VW> struct BVec;
 template <> struct BVec<1> { typedef float T; };
 template <> struct BVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct BVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+// Stores / max-combines the VW values a lane holds for ONE pooled row: VW CONSECUTIVE columns (4 l31 + t inside a group of
+// 32 VW columns: the column map of tile_col, which follows from the 16-byte B-fragment loads).
+//  * single-part centres: one 8- / 16-byte store per lane, the half-wave covers the group's 32 VW columns contiguously
+//    (round 2: VW dword stores per lane, each instruction touching every VW-th dword of the span);
+//  * multi-part centres (integer atomic max): the values go through the wave's LDS scratch so that every atomic instruction
+//    covers 32 CONTIGUOUS columns = two 64-byte memory-side requests instead of 2 VW partly used ones (the atomics of this
+//    kernel were 499 of the pass's 786 MB of memory-side writes: profiles/r02_zm_pmc_summary.json).
+// Must be called by all 64 lanes (tag < 0: nothing to store for this lane's half); tags are uniform per half.
+template <int VW>
+__device__ __forceinline__ void g_store_group(float *rowptr, const float (&v)[VW], const int tag, float *__restrict__ scr,
+                                              const int lane, const int yvec) {
+  const bool live = tag >= 0;
+  const int l31 = lane & 31;
+  if constexpr (VW == 1) {
+    if (live) g_store(rowptr + l31, v[0], tag);
+  } else {
+    if (!yvec) {
+#pragma unroll
+      for (int t = 0; t < VW; ++t)
+        if (live) g_store(rowptr + VW * l31 + t, v[t], tag);
+      return;
+    }
+    const bool atomic = live && (tag & 0x20000000);
+    typename BVec<VW>::T pack;
+#pragma unroll
+    for (int t = 0; t < VW; ++t) pack[t] = v[t];
+    if (live && !atomic) *reinterpret_cast<typename BVec<VW>::T *>(rowptr + VW * l31) = pack;
+    if (__ballot(atomic) != 0ull) {                       // wave-uniform
+      *reinterpret_cast<typename BVec<VW>::T *>(scr + lane * VW) = pack;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      const float *half = scr + (lane & 32) * VW;         // this half's 32 VW values, column order
+      float x[VW];
+#pragma unroll
+      for (int t = 0; t < VW; ++t) x[t] = half[32 * t + l31];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();                    // the scratch may be rewritten by the next call
+      if (atomic) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t)
+          __hip_atomic_fetch_max(reinterpret_cast<int *>(rowptr + 32 * t + l31), __builtin_bit_cast(int, x[t]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
 
 template <int VW>
 __device__ __forceinline__ typename BVec<VW>::T load_b(const __amdgpu_buffer_rsrc_t srd, uint32_t voff, int soff) {
@@ -239,7 +287,11 @@ __device__ __forceinline__ void group_layer1(const GroupArgs &g, const int tile,
 template <int TN3, bool COMPACT>
 __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int tile, f32x16 (&acc)[TN3], const float (&sh3)[TN3],
                                                  const int colbase, const int l31, const int kh, const int h1, const int h2,
-                                                 const int h3, const int h4, const int h5, const int *__restrict__ tagbuf) {
+                                                 const int h3, const int h4, const int h5, const int *__restrict__ tagbuf,
+                                                 float *__restrict__ scr) {
+    constexpr int VW = TN3 >= 4 ? 4 : TN3;            // consecutive columns per lane (tile_col)
+    constexpr int NG = TN3 / VW;                      // groups of 32 VW columns
+    const int lane = l31 + 32 * kh;
     if (COMPACT) {
       const int sc = g_class(tile * 32, h1, h2, h3, h4, h5);
       if (sc < 4) {       // classes 1, 2: every accumulator (pair) is a centre part of its own
@@ -247,12 +299,17 @@ __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int t
         for (int e = 0; e < 16; ++e) {
           if (sc == 2 && (e & 1)) continue;
           const int tag = tagbuf[(e & 3) + 8 * (e >> 2) + 4 * kh];
-          if (tag < 0) continue;
-          float *dst = g.y + (size_t)(tag & 0x1fffffff) * g.ldy + g.col0 + colbase;
+          float *dst = g.y + (size_t)(tag < 0 ? 0 : tag & 0x1fffffff) * g.ldy + g.col0 + colbase;
 #pragma unroll
-          for (int j = 0; j < TN3; ++j) {
-            const float raw = sc == 2 ? d6_vmax(acc[j][e], acc[j][e + 1 < 16 ? e + 1 : e]) : acc[j][e];
-            g_store(dst + tile_col<TN3>(j, l31), (tag & 0x40000000) ? 0.f : d6_relu(raw + sh3[j]), tag);
+          for (int jg = 0; jg < NG; ++jg) {
+            float v[VW];
+#pragma unroll
+            for (int t = 0; t < VW; ++t) {
+              const int j = jg * VW + t;
+              const float raw = sc == 2 ? d6_vmax(acc[j][e], acc[j][e + 1 < 16 ? e + 1 : e]) : acc[j][e];
+              v[t] = (tag & 0x40000000) ? 0.f : d6_relu(raw + sh3[j]);
+            }
+            g_store_group<VW>(dst + jg * 32 * VW, v, tag, scr, lane, g.yvec);
           }
         }
       } else {
@@ -263,41 +320,55 @@ __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int t
           oc[qq] = rr >= 0 ? tagbuf[rr] : -1;
         }
 #pragma unroll
-        for (int j = 0; j < TN3; ++j) {
-          float q[4];
+        for (int jg = 0; jg < NG; ++jg) {
+          float q[VW][4];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            q[qq] = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
-          g_pool(q, sc);
+          for (int t = 0; t < VW; ++t) {
+            const int j = jg * VW + t;
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            if (oc[qq] >= 0)
-              g_store(g.y + (size_t)(oc[qq] & 0x1fffffff) * g.ldy + g.col0 + colbase + tile_col<TN3>(j, l31),
-                      (oc[qq] & 0x40000000) ? 0.f : d6_relu(q[qq] + sh3[j]), oc[qq]);
+            for (int qq = 0; qq < 4; ++qq)
+              q[t][qq] = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
+            g_pool(q[t], sc);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            float v[VW];
+#pragma unroll
+            for (int t = 0; t < VW; ++t) v[t] = (oc[qq] & 0x40000000) ? 0.f : d6_relu(q[t][qq] + sh3[jg * VW + t]);
+            float *dst = g.y + (size_t)(oc[qq] < 0 ? 0 : oc[qq] & 0x1fffffff) * g.ldy + g.col0 + colbase + jg * 32 * VW;
+            g_store_group<VW>(dst, v, oc[qq], scr, lane, g.yvec);
+          }
         }
       }
     } else {
       // dense rows: a tile is one centre (nsample 32) or two (nsample 16); empty balls pool to 0
       const int c0 = g.ns == 32 ? tile : 2 * tile;
       const int cnt0 = g.cnt[c0], cnt1 = g.ns == 32 ? 0 : g.cnt[c0 + 1];
+      const int plain = kh == 0 ? 0 : -1;              // lanes of half 0 store (tag 0: a plain store), half 1 holds the same values
 #pragma unroll
-      for (int j = 0; j < TN3; ++j) {
-        float q[4];
+      for (int jg = 0; jg < NG; ++jg) {
+        float v0[VW], v1[VW];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const float mq = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
-          q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
-        }
-        float *dst = g.y + g.col0 + colbase + tile_col<TN3>(j, l31);
-        if (kh == 0) {
+        for (int t = 0; t < VW; ++t) {
+          const int j = jg * VW + t;
+          float q[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const float mq = d6_vmax(d6_vmax(acc[j][4 * qq], acc[j][4 * qq + 1]), d6_vmax(acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
+            q[qq] = d6_vmax(mq, __shfl_xor(mq, 32));
+          }
           if (g.ns == 32) {
             const float mx = d6_relu(d6_vmax(d6_vmax(q[0], q[1]), d6_vmax(q[2], q[3])) + sh3[j]);
-            dst[(size_t)c0 * g.ldy] = cnt0 > 0 ? mx : 0.f;
+            v0[t] = cnt0 > 0 ? mx : 0.f;
+            v1[t] = 0.f;
           } else {
-            dst[(size_t)c0 * g.ldy] = cnt0 > 0 ? d6_relu(d6_vmax(q[0], q[1]) + sh3[j]) : 0.f;
-            dst[(size_t)(c0 + 1) * g.ldy] = cnt1 > 0 ? d6_relu(d6_vmax(q[2], q[3]) + sh3[j]) : 0.f;
+            v0[t] = cnt0 > 0 ? d6_relu(d6_vmax(q[0], q[1]) + sh3[j]) : 0.f;
+            v1[t] = cnt1 > 0 ? d6_relu(d6_vmax(q[2], q[3]) + sh3[j]) : 0.f;
           }
         }
+        float *dst = g.y + g.col0 + colbase + jg * 32 * VW;
+        g_store_group<VW>(dst + (size_t)c0 * g.ldy, v0, plain, scr, lane, g.yvec);
+        if (g.ns != 32) g_store_group<VW>(dst + (size_t)(c0 + 1) * g.ldy, v1, plain, scr, lane, g.yvec);
       }
     }
 }
@@ -313,6 +384,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
   int *tags = reinterpret_cast<int *>(lds + 32 * (LD1 + LD2));    // 2 x 32 row tags, by tile parity (no barrier between a tile's
   int it = 0;                                                     // epilogue and the next tile's first layer)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  float *scr = reinterpret_cast<float *>(tags + 64) + wave * (64 * (TN3 >= 4 ? 4 : TN3));   // wave-private: g_store_group
   const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   if ((int)blockIdx.x >= live_tiles) return;
   int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
@@ -378,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
     third.run(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
     D6_WAVE_T1(ph_w3);
     D6_PHASE(3);
-    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / NW), l31, kh, h1, h2, h3, h4, h5, tagbuf);
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / NW), l31, kh, h1, h2, h3, h4, h5, tagbuf, scr);
     // no barrier here: the next tile's layer 1 writes X1, which every wave finished reading before the barrier above;
     // X2 is rewritten only after the next tile's first barrier, which no wave passes before it has left layer 3
     D6_PHASE(4);
@@ -457,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
   int *tags = reinterpret_cast<int *>(Y1 + 32 * LDY);             // 2 x 32 row tags, by tile parity
   int it = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  float *scr = reinterpret_cast<float *>(tags + 64) + wave * (64 * 4);                      // wave-private: g_store_group
   const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   if ((int)blockIdx.x >= live_tiles) return;
   int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
@@ -506,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
         __syncthreads();
       }
     }
-    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5, tagbuf);
+    group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5, tagbuf, scr);
     // no barrier here: X1 is rewritten by the next tile's layer 1, every wave is past its last second-layer chunk (the
     // barrier above); Y0 is rewritten after the next tile's first barrier, Y1 two barriers later
   }
@@ -514,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
 
 template <int C1, int C2, int C3, bool COMPACT>
 int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
-  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64);
+  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64 + 4 * 64 * 4);   // + tags + store scratch
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void *)mlp_group_stream_kernel<C1, C2, C3, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -528,7 +601,8 @@ int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
 
 template <int C1, int C2, int C3, bool COMPACT, int NW>
 int launch_group(const GroupArgs &g, hipStream_t stream) {
-  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + C2 + 1) + 64);
+  constexpr int kTN3 = C3 / (32 * NW);
+  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + C2 + 1) + 64 + NW * 64 * (kTN3 >= 4 ? 4 : kTN3));   // + tags + store scratch
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void *)mlp_group_kernel<C1, C2, C3, COMPACT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -598,6 +672,7 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   g.y = y; g.ldy = ldy; g.col0 = col0;
   static const int pre_entries = det6d_switch_int("DET6D_GROUP_PRE", 1);
   g.pre = pre_entries;
+  g.yvec = (!(ldy & 3) && !(col0 & 3) && !((uintptr_t)y & 15)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   // waves per 32-row tile: 8 for the head's groups (two waves per SIMD from ONE workgroup: the 99 KB of LDS allow only one
   // workgroup per CU), 4 for the SA3 groups (several workgroups per CU); DET6D_GROUP_WAVES (experiments build) overrides
