@@ -106,9 +106,12 @@ def fps_is_cooperative(n):
 
 def fps_workspace(b, n, device='cuda'):
     """scratch of one sampler launch over b scenes of n points (det6d_fps_fused_workspace_bytes: (b, n) floats, more for
-    the cooperative sampler of 32768 / 65536-point scenes), zero-filled: the cooperative sampler's error word is sticky
-    and cleared only here and by a status read"""
-    return torch.zeros((int(L.lib().det6d_fps_fused_workspace_bytes(b, n)),), dtype=torch.uint8, device=device)
+    the cooperative sampler of 32768 / 65536-point scenes).  A cooperative workspace is zero-filled: its error word is
+    sticky and cleared only here and by a status read (the other samplers cannot fail after their launch: no fill)"""
+    nbytes = int(L.lib().det6d_fps_fused_workspace_bytes(b, n))
+    if nbytes > 4 * b * n:
+        return torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
 
 
 def gather_centres(xyz, idx, rows_out=None, zero_from=0, out=None, idx_bias=0):
