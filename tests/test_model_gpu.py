@@ -265,3 +265,40 @@ def test_determinism_and_batch_shapes(oracle_ops):
         with torch.no_grad():
             single, _ = model({'batch_size': 1, 'points': pts[:2048].clone()})
         assert torch.equal(single[0]['pred_boxes'], outs[0][0]['pred_boxes'])
+
+
+def test_degenerate_scenes_through_the_whole_model(oracle_ops):
+    """scenes the reference's `sample_points` padding and sparse frames produce in the extreme: every point identical (all
+    distances 0: every FPS round is a tie, every ball is full of one point), two distinct points, an exact lattice (ties in every
+    sampler and in every ball-query distance test), a dense blob (every ball capped at nsample, hundreds of hits per shell).
+    Tiny widths, 2048 points, through the eager model AND the full-width model on 16384 points for the blob; bit-exact."""
+    from de6d_amd.runtime import load_config, build_model
+    from oracle import model as omodel
+    rng = np.random.default_rng(3)
+    n = 2048
+    same = np.tile(np.array([[12.0, 3.0, -1.0, 0.5]], np.float32), (n, 1))
+    two = same.copy(); two[1::2] = [12.4, 3.2, -0.9, 0.1]
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing='ij'), -1).reshape(-1, 3)[:n]
+    lattice = np.concatenate([g * np.float32(0.25) + np.float32([5, -2, -2]), np.full((n, 1), 0.3)], 1).astype(np.float32)
+    blob = np.concatenate([rng.normal(size=(n, 3)) * [1.0, 1.0, 0.2] + [20, 0, -1], rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    cfg = load_config('synthetic_models/det6d_tiny.yaml')
+    model = build_model(cfg, seed=17, device='cuda')
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    batch = np.stack([same, two, lattice, blob], 0)
+    pts = flat_points(batch)
+    bd = {'batch_size': 4, 'points': torch.from_numpy(pts).cuda()}
+    with torch.no_grad():
+        pred, _ = model(bd)
+    check(bd, pred, omodel.forward(cfg.MODEL, sd, pts, 4), 4)
+    # full width, 16384 points: a dense blob beside a normal scene (every SA1 ball of the blob is capped)
+    cfg = load_config('kitti_models/det6d_car.yaml')
+    model = build_model(cfg, seed=18, device='cuda')
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    n = 16384
+    blob = np.concatenate([rng.normal(size=(n, 3)) * [2.0, 2.0, 0.3] + [20, 0, -1], rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    batch = np.stack([blob, make_batch(77, 1, n)[0]], 0)
+    pts = flat_points(batch)
+    bd = {'batch_size': 2, 'points': torch.from_numpy(pts).cuda()}
+    with torch.no_grad():
+        pred, _ = model(bd)
+    check(bd, pred, omodel.forward(cfg.MODEL, sd, pts, 2), 2)

@@ -291,17 +291,19 @@ def test_bench_entry_point_checks_itself():
     assert d['config']['batches_per_pass'] == 4 and d['config']['scenes_per_pass'] == 32      # 8 steps = 2 coalesced passes
 
 
-def test_ray_cast_batch8_through_scene_pipeline_vs_oracle(oracle_ops):
-    """the `--scene beam` leg as bench.py times it: batch 8 x 16384 ray-cast scenes, coalesced 32-scene passes through
-    ScenePipeline (KITTI-like ball fill 0.3-0.9: the GEMM-bound regime), every step against the ORACLE's dense rows bit for
-    bit — the 64-row mlp_rows tiles, the 2048-workgroup chain grids and the full-ball class-32 tiles of the compact lists
-    only occur at these row counts"""
+@pytest.mark.parametrize("scene", ["beam", "uniform"])
+def test_coalesced_32_scene_passes_through_scene_pipeline_vs_oracle(oracle_ops, scene):
+    """what bench.py's `value` (uniform scenes) and its `--scene beam` leg (ray-cast scenes, KITTI-like ball fill 0.3-0.9: the
+    GEMM-bound regime) time: batch 8 x 16384, four batches coalesced into 32-scene passes through ScenePipeline, every step
+    against the ORACLE's dense rows bit for bit — the 64-row mlp_rows tiles, the 2048-workgroup chain grids and (ray-cast) the
+    full-ball class-32 tiles of the compact lists only occur at these row counts"""
     from de6d_amd.runtime import load_config, build_model, ScenePipeline
     from tests.util import beam_batch
     cfg = load_config('kitti_models/det6d_car.yaml')
     model = build_model(cfg, seed=1234, device='cuda')
     b, n, merge = 8, 16384, 4
-    batches_np = [flat_points(beam_batch(4300 + 20 * j, b, n)) for j in range(merge)]
+    make = beam_batch if scene == "beam" else make_batch
+    batches_np = [flat_points(make(4300 + 20 * j, b, n)) for j in range(merge)]
     batches = [torch.from_numpy(p).cuda() for p in batches_np]
     inputs = ScenePipeline.coalesce(batches, merge)                      # one 32-scene pass input
     pipe = ScenePipeline(model, b, n, n_main=4, group=1, prefetch=2, sampler_streams=2, points=inputs, merge=merge)
