@@ -232,6 +232,10 @@ def main():
         args.streams = 16
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # (torch.cuda.device_count() does not initialise the GPU)
+        if args.gpus > torch.cuda.device_count() and os.environ.get('DET6D_BENCH_BACKEND') != 'gloo':
+            raise SystemExit("bench.py: --gpus %d but %d visible device(s): one process per GPU (DET6D_BENCH_BACKEND=gloo allows a "
+                             "dry run on shared devices)" % (args.gpus, torch.cuda.device_count()))
         raise SystemExit(spawn_ranks(args.gpus))       # nothing above has initialised HIP
     if 'WORLD_SIZE' not in os.environ and not args.worker and not args.no_legs:
         raise SystemExit(orchestrate(args))            # legs run in processes of their own, one at a time (see orchestrate)
@@ -242,8 +246,12 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count() and os.environ.get('DET6D_BENCH_BACKEND') != 'gloo':
-        raise SystemExit("bench.py: LOCAL_RANK %d but %d visible device(s): one process per GPU" % (local_rank, torch.cuda.device_count()))
+    # every rank takes this decision from the same numbers BEFORE the rendezvous: a rank that left alone would keep the others
+    # waiting for the store's time-out (10 minutes)
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    if local_world > torch.cuda.device_count() and os.environ.get('DET6D_BENCH_BACKEND') != 'gloo':
+        raise SystemExit("bench.py: %d ranks on this node but %d visible device(s): one process per GPU "
+                         "(DET6D_BENCH_BACKEND=gloo allows a dry run on shared devices)" % (local_world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
     ranks_seen = [device_identity()]

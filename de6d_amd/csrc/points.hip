@@ -112,25 +112,18 @@ __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
 }
 
 // out[b,c,i] = fma(w2,p2, fma(w0,p0, w1*p1))   (contraction order: oracle/det6d_oracle.c)
-// one thread per (scene, point, chunk of kInterpChunk channels): the point's three indices and weights are loaded once and
-// reused for every channel of the chunk (round 2: one thread per output element re-read all six for each of the c channels:
-// 1.5 KB of index / weight reads per point at c = 64, 0.85 TB/s of algorithmic bytes); stores are coalesced over the points.
-// Arithmetic per element unchanged: fma(w2, p2, fma(w0, p0, w1 * p1)).
-constexpr int kInterpChunk = 16;
-__global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+__global__ void three_interpolate_kernel(int64_t total, int c, int m, int n,
+                                         const float *__restrict__ points, const int *__restrict__ idx,
                                          const float *__restrict__ weight, float *__restrict__ out) {
-  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pt >= n) return;
-  const int64_t bi = blockIdx.z;
-  const int c0 = blockIdx.y * kInterpChunk, c1 = min(c0 + kInterpChunk, c);
-  const float *w = weight + (bi * n + pt) * 3;
-  const int *id = idx + (bi * n + pt) * 3;
-  const float w0 = w[0], w1 = w[1], w2 = w[2];
-  const int i0 = id[0], i1 = id[1], i2 = id[2];
-  const float *p = points + (bi * c + c0) * m;
-  float *o = out + (bi * c + c0) * n + pt;
-#pragma unroll 4
-  for (int ch = c0; ch < c1; ++ch, p += m, o += n) *o = D6_FMA(w2, p[i2], D6_FMA(w0, p[i0], w1 * p[i1]));
+  GRID_STRIDE(i, total) {
+    const int pt = (int)(i % n);
+    const int64_t bc = i / n;
+    const int64_t bi = bc / c;
+    const float *w = weight + (bi * n + pt) * 3;
+    const int *id = idx + (bi * n + pt) * 3;
+    const float *p = points + bc * m;
+    out[i] = D6_FMA(w[2], p[id[2]], D6_FMA(w[0], p[id[0]], w[1] * p[id[1]]));
+  }
 }
 
 __global__ void three_interpolate_grad_kernel(int64_t total, int c, int n, int m,
@@ -320,9 +313,8 @@ DET6D_API int det6d_three_interpolate(int b, int c, int m, int n, const float *p
   if (b < 0 || c < 0 || n < 0 || m < 0 || !points || !idx || !weight || !out) return DET6D_EINVAL;
   const int64_t total = (int64_t)b * c * n;
   if (total == 0) return DET6D_OK;
-  if (b > 65535 || det6d_divup(c, kInterpChunk) > 65535) return DET6D_EINVAL;
-  hipLaunchKernelGGL(three_interpolate_kernel, dim3(det6d_divup(n, kBlock), det6d_divup(c, kInterpChunk), b), dim3(kBlock), 0,
-                     S(stream), c, m, n, points, idx, weight, out);
+  hipLaunchKernelGGL(three_interpolate_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, m,
+                     n, points, idx, weight, out);
   return det6d_check_launch("det6d_three_interpolate");
 }
 

@@ -513,9 +513,11 @@ class Det6DGroup(object):
         return self.launch_front(points, count).launch_rest()
 
 
-#: CUs the cooperative samplers in flight may occupy together (256 on MI355X, one 1024-thread workgroup each; margin for
-#: CUs whose LDS / registers other long-running workgroups hold)
-COOP_CUS = 224
+#: Workgroups of the cooperative samplers that may be in flight together, as a fraction of the device's CUs (one 1024-thread
+#: workgroup holds a CU).  1.0 is exact, not optimistic: with at most #CUs such workgroups in flight, a launch that is partly
+#: resident can hold at most (#CUs - the other launches' sizes) CUs, so every launch can always become fully resident once the
+#: kernels that do not wait for anybody have drained; beyond #CUs, partly resident launches can starve each other.
+COOP_CU_FRACTION = 1.0
 
 
 def warn_hw_queues(need):
@@ -568,11 +570,12 @@ class ScenePipeline(object):
         if fused.fps_is_cooperative(n_points):
             # The cooperative sampler of 32768 / 65536-point scenes needs ALL parts of a scene resident at once (they
             # poll each other).  Launches on different streams may be dispatched interleaved, so the launches in flight
-            # together must fit the chip with one 1024-thread workgroup per CU (COOP_CUS with a margin): stage 1 of the
+            # together must fit the chip with one 1024-thread workgroup per CU (COOP_CU_FRACTION): stage 1 of the
             # groups shares as few sampler streams as that allows (launches on one stream never overlap; inside one
             # launch the parts of a scene are consecutive in dispatch order).
             per_launch = min(group, n_main) * batch_size * (n_points // 16384)
-            self.sampler_streams = self.sampler_streams[:max(1, COOP_CUS // max(1, per_launch))]
+            cus = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * COOP_CU_FRACTION)
+            self.sampler_streams = self.sampler_streams[:max(1, cus // max(1, per_launch))]
         n_main = len(self.main_streams)
         self.n_groups = max(1, n_main // self.k) + prefetch
         self.groups = []

@@ -418,10 +418,11 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  *                 alignment rows).
  * split = g > 0 (a power of two >= smin): a centre with more than g hits takes ceil(cnt / g) * g rows, cut along their
  * binary digits into parts of descending size (20 = 16 + 4), each a group of its class; consumers combine the parts'
- * maxima with an integer atomic max on the non-negative post-ReLU values, so the pooled buffer must be ZEROED before
- * the pooled layer runs.  Centres with <= g hits stay one part of the next power of two >= max(cnt, smin).
- * zero_y != NULL: columns [col0, col0 + width) of the (B*m, ldy) pooled buffer are cleared by this call (all multiples
- * of 4), which saves the separate fill. */
+ * maxima with an integer atomic max on the non-negative post-ReLU values, so the pooled rows of MULTI-PART centres must be
+ * ZERO before the pooled layer runs; a single-part centre's row is written whole by a plain store.  Centres with <= g hits
+ * stay one part of the next power of two >= max(cnt, smin).
+ * zero_y != NULL: columns [col0, col0 + width) of the rows of the multi-part centres in the (B*m, ldy) pooled buffer are
+ * cleared by this call (all multiples of 4), which saves the separate fill. */
 int det6d_compact_rows_capacity(int total_centres, int ns);
 int det6d_compact_hdr_ints(int total_centres);   /* ints the hdr buffer must hold (16 header words + scratch) */
 int det6d_compact_groups(int b, int n, int m, int ns, int smin, int split, const int *cnt, const int *idx, int *hdr,

@@ -19,8 +19,22 @@ def short(n):
     return out[:70]
 t0 = min(int(r['Start_Timestamp']) for r in rows)
 t1 = max(int(r['End_Timestamp']) for r in rows)
-# steady window: the middle half of the trace
-lo, hi = t0 + (t1 - t0) * 0.55, t0 + (t1 - t0) * 0.9
+# steady window: the stretch of the trace with the most kernels in flight — 50 ms bins whose summed kernel time is at least
+# half the maximum, the longest contiguous run of them (the process also runs eager warm-up / self-check / latency passes on
+# one stream, with at most one kernel in flight, and idles between its legs)
+nb = max(1, int((t1 - t0) / 50e6) + 1)
+hist = [0.0] * nb
+for r in rows:
+    hist[min(nb - 1, int((int(r['Start_Timestamp']) - t0) / 50e6))] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+thr, best, cur = max(hist) * 0.5, (0, 0), None
+for i, hcount in enumerate(hist + [0]):
+    if hcount >= thr and cur is None:
+        cur = i
+    elif hcount < thr and cur is not None:
+        if i - cur > best[1] - best[0]:
+            best = (cur, i)
+        cur = None
+lo, hi = t0 + best[0] * 50e6 + 0.1 * (best[1] - best[0]) * 50e6, t0 + best[1] * 50e6 - 0.05 * (best[1] - best[0]) * 50e6
 agg = defaultdict(lambda: [0, 0.0, 0.0, 1e30, 0.0])
 for r in rows:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])

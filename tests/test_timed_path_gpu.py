@@ -344,7 +344,8 @@ def test_cooperative_sampler_pipeline_under_load_reports_status(oracle_ops):
         eager = [model({'batch_size': b, 'points': p})[0] for p in batches]
     torch.cuda.synchronize()
     pipe = ScenePipeline(model, b, n, n_main=4, group=1, prefetch=2, sampler_streams=6, points=batches)
-    assert len(pipe.sampler_streams) <= 224 // (b * 4)       # bounded: 8 cooperative workgroups per launch here
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert len(pipe.sampler_streams) <= max(1, cus // (b * 4))       # bounded: 8 cooperative workgroups per launch here
     assert all(g._status_words for g in pipe.groups)          # every group watches its sampler's error word
     # background load: 16 streams of large GEMMs for the whole run
     x = torch.randn((8192, 1024), device='cuda')
