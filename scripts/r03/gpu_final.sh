@@ -22,4 +22,4 @@ for l in open('gpurun_out/r03_final/bench_2ranks.log'):
     if l.startswith('{'):
         d = json.loads(l); print('2 ranks on one GPU (gloo dry run):', d['n_gpus'], d['value'], d['per_rank_scenes_per_s'], d['selfcheck'], d['ranks_seen'])
 PY
-python3 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r03_final/bench_2ranks_nccl.log 2>&1; echo "rc of --gpus 2 with ONE device (must be non-zero): $?"; tail -2 gpurun_out/r03_final/bench_2ranks_nccl.log
+timeout 120 python3 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r03_final/bench_2ranks_nccl.log 2>&1; echo "rc of --gpus 2 with ONE device (must be non-zero): $?"; tail -2 gpurun_out/r03_final/bench_2ranks_nccl.log
