@@ -516,3 +516,17 @@ def test_fallback_kernels_via_env_switches(tmp_path):
                           '-k', 'test_linear or (chain3 and not widths4 and not widths5 and not widths6 and not widths7)'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout
+
+
+@pytest.mark.parametrize("b,n,m,c", [(2, 16384, 4096, 64), (1, 300, 50, 3), (1, 2048, 16384, 5), (3, 1024, 4093, 7), (2, 5000, 512, 4)])
+def test_three_interpolate_shapes(ext, oracle_ops, b, n, m, c):
+    """both forms of det6d_three_interpolate (channel rows staged in LDS when four of them fit 64 KB and n >= 1024, the plain
+    gather otherwise; odd m: unaligned rows) against the oracle, bit for bit"""
+    pn = ext[0]
+    rng = np.random.default_rng(n + m)
+    feats = rng.normal(size=(b, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    out = torch.empty((b, c, n), device="cuda")
+    pn.three_interpolate_wrapper(b, c, m, n, dev(feats), dev(idx), dev(w), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle_ops.three_interpolate(feats, idx, w))
