@@ -25,7 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kChainWaves = 4;
-constexpr int kPackTiles = 1;    // compact lists: tiles per wave before another workgroup is used (1: 9970, 2: 9910, 4: 9780 scenes/s)
+constexpr int kPackTiles = 1;    // compact lists: tiles a wave must get before another workgroup is used (1: 9970, 2: 9910, 4: 9780 scenes/s)
 constexpr int kTS = 33;       // row stride of the wave-private [channel][row] tiles
 constexpr int kMaxK1 = 8;     // input row width (x,y,z,features + pad)
 constexpr int kMaxC = 32;     // hidden widths
@@ -528,9 +528,9 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
   float *W2 = W1 + (K1 + 2) * C1;           // (C1 + 2) x C2
   float *W3 = W2 + (C1 + 2) * C2;           // C2 x C3
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-  // compact lists: the grid is sized for the capacity but the list holds a fraction of it.  Its tiles are PACKED onto few
-  // workgroups — at least kPackTiles tiles per wave, workgroup w owns tiles [w * 8T, (w + 1) * 8T) — so that the 66-92 KB
-  // of weights are staged by ~35 workgroups instead of 256 (SA2, batch 8); the others leave before staging.
+  // compact lists: the grid is sized for the capacity but the list holds a fraction of it: only the workgroups that get at
+  // least kPackTiles tiles per wave stay (the others leave before staging the 66-92 KB of weights); the live tiles are
+  // dealt round them, tile t -> wave t mod (active waves).
   int pk_stride = 0, pk_first = 0, pk_end = 0;
   if (COMPACT) {   // tile t -> wave t mod (active waves): every workgroup sees the same mix of classes (see mlp_chain_reg_kernel)
     const int wpw = blockDim.x >> 6, live = g.hdr[0] / 32;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) 
       e_p = g.idx[t * 32 + l31];
     }
   };
-  auto fetch = [&](int t) {   // t wave-uniform; consumes the entries fetch_entries(t) left in e_p / e_c / e_oc
+  auto fetch = [&](int t) {   // t wave-uniform; consumes the entries fetch_entries(t) left in e_p / e_c
     if (COMPACT) {
       const int p = e_p;
       const float *row = g.a + (size_t)p * K1;
