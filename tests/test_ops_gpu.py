@@ -417,6 +417,12 @@ def test_cooperative_sampler_for_large_scenes():
                          timeout=900, env=dict(os.environ, DET6D_FPS_COOP="0"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout and "fallback" in out.stdout, out.stdout
+    # DET6D_FPS_COOP_AGENT=1: agent-scope publishing stores whatever the placement of a scene's parts (the default publishes
+    # with workgroup-scope stores when the parts share an XCD: a gfx950 write-through-L1 property, not a memory-model promise)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py")], capture_output=True, text=True,
+                         timeout=1500, env=dict(os.environ, DET6D_FPS_COOP_AGENT="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALL True" in out.stdout and "fallback" not in out.stdout, out.stdout
 
 
 def test_ball_query_grid_adversarial(ext, oracle_ops):
