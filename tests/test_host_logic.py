@@ -240,3 +240,19 @@ def test_mlp_rows_supported_query_mirrors_the_launch_checks():
     assert not fused.mlp_rows_eligible(96, [[(z(96, 50), 0, None, 96, 50, 1, None, 0), (z(50, 4), 0, None, 50, 1, 0, z(4, 4), 0)]])   # hidden width % 32
     assert not fused.mlp_rows_eligible(256, [[(z(256, 128), 0, None, 256, 128, 1, None, 0)]])    # last layer without an output
     assert not fused.mlp_rows_eligible(256, ok + ok + ok)                                           # three chains
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`bench.py --gpus N` with fewer than N visible devices exits non-zero BEFORE any rank is started or any rendezvous is
+    attempted (a rank that left alone would keep the others waiting for the store's ten-minute time-out); decided from
+    torch.cuda.device_count(), which does not initialise the GPU.  Here: no device at all."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a machine with fewer than two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DET6D_BENCH_BACKEND')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert 'visible device' in (out.stderr + out.stdout)
