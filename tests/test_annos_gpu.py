@@ -124,3 +124,34 @@ def test_eval_one_epoch_end_to_end(tmp_path):
         lines = (tmp_path / 'final_result' / 'data' / ('%s.txt' % a['frame_id'])).read_text().splitlines()
         assert len(lines) == k and all(len(ln.split(' ')) == 18 for ln in lines)
     assert sum(len(a['name']) for a in annos) > 0
+
+
+def test_padded_result_block_fast_path_equals_the_generic_path():
+    """captured passes hand out per-frame views of one padded (B, P, C) block: convert_batch converts the whole block with
+    one launch (no per-frame concatenation); a sub-range of the block's frames (a step of a coalesced pass), frames with no
+    detections, and tensors that are NOT such views (generic path) must all give the same annotation dictionaries"""
+    from de6d_amd.pcdet import datasets
+    from de6d_amd.pcdet.datasets.kitti import kitti_dataset as kd
+    from de6d_amd.pcdet.utils.calibration_kitti import Calibration
+    rng = np.random.default_rng(9)
+    nb, pmax, ncol = 6, 100, 9
+    calibs = [Calibration({'P2': GOLD['in_%d_P2' % (i % N_FRAMES)], 'R0': GOLD['in_%d_R0' % (i % N_FRAMES)],
+                           'Tr_velo2cam': GOLD['in_%d_Tr_velo2cam' % (i % N_FRAMES)]}) for i in range(nb)]
+    boxes = torch.from_numpy((rng.normal(size=(nb, pmax, ncol)) * [10, 5, 1, 1, 1, 1, 1, 0.1, 0.1] + [25, 0, -1, 4, 2, 1.5, 0, 0, 0]).astype(np.float32)).cuda()
+    scores = torch.from_numpy(rng.uniform(0.1, 1, (nb, pmax)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rng.integers(1, 4, (nb, pmax))).cuda()
+    counts = [100, 0, 37, 1, 64, 5]
+    views = [{'pred_boxes': boxes[i, :k], 'pred_scores': scores[i, :k], 'pred_labels': labels[i, :k]} for i, k in enumerate(counts)]
+    copies = [{k_: v.clone() for k_, v in p.items()} for p in views]
+    for lo, hi in ((0, 6), (2, 5), (1, 2)):
+        batch = {'frame_id': ['%06d' % i for i in range(lo, hi)], 'calib': calibs[lo:hi],
+                 'image_shape': np.tile(np.array([[375, 1242]], np.int32), (hi - lo, 1))}
+        assert kd._padded_block(views[lo:hi]) is not None
+        assert kd._padded_block(copies[lo:hi]) is None
+        fast = datasets.SlopedKittiDataset.generate_prediction_dicts(batch, views[lo:hi], NAMES)
+        slow = datasets.SlopedKittiDataset.generate_prediction_dicts(batch, copies[lo:hi], NAMES)
+        assert len(fast) == len(slow) == hi - lo
+        for a, b in zip(fast, slow):
+            assert a.keys() == b.keys()
+            for key in a:
+                assert np.array_equal(a[key], b[key]), key
