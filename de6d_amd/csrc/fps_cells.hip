@@ -434,6 +434,10 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsign
 }
 #endif
 
+// fps_seq.hip: the look-ahead sampler (sequencer wave + asynchronous region owners)
+int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, long long xyz_bstride, long long idx_bstride,
+                         int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream);
+
 // Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
                            long long idx_bstride, int idx_add, int init_temp, const float *xyz,
@@ -443,6 +447,12 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
   // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
   static const int skip = det6d_switch_int("DET6D_FPS_SKIP", 16);
+  // DET6D_FPS_SEQ: regions per owner wave of the look-ahead sampler (fps_seq.hip; 1, 2 or 3), 0 = the wave-skip sampler below
+  static const int seq = det6d_switch_int("DET6D_FPS_SEQ", 2);
+  if (seq && n == 16384 && init_temp) {
+    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    return det6d_fps_seq_launch(b, n, m, log2s, seq >= 1 && seq <= 3 ? seq : 2, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
+  }
   if (skip && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
     // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two

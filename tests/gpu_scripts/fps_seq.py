@@ -1,0 +1,56 @@
+"""Look-ahead sampler (csrc/fps_seq.hip) against the oracle + timing; run once per DET6D_FPS_SEQ value (the switch is read
+once per process): python tests/gpu_scripts/fps_seq.py [quick]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from de6d_amd import _lib as L
+from de6d_amd.ops import fused
+from oracle import ops as oops
+from tests.util import make_batch, beam_batch
+
+def timeouts():
+    return L.lib().det6d_fps_seq_timeouts()
+
+def run(name, xyz, m, check=2, reps=5):
+    b, n, _ = xyz.shape
+    x = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+    idx = torch.zeros((b, m), dtype=torch.int32, device='cuda')
+    temp = fused.fps_workspace(b, n)
+    fused.fps_fused(x, 0, n, m, None, 1.0, idx, 0, temp=temp); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fused.fps_fused(x, 0, n, m, None, 1.0, idx, 0, temp=temp)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    ok = None
+    if check:
+        ref = oops.fps(xyz[:check], m)
+        got = idx.cpu().numpy()[:check]
+        ok = np.array_equal(got, ref)
+        if not ok:
+            bad = np.argwhere(got != ref)
+            print('   first mismatch at', bad[0], got[tuple(bad[0])], ref[tuple(bad[0])], 'of', len(bad))
+    print("%-28s b=%d n=%d m=%d: %.3f ms (%.3f us/round) exact=%s timeouts=%d" % (name, b, n, m, best * 1e3, best * 1e6 / m, ok, timeouts()), flush=True)
+    return ok
+
+print('DET6D_FPS_SEQ =', os.environ.get('DET6D_FPS_SEQ'))
+quick = 'quick' in sys.argv
+n = 16384
+good = True
+u = np.ascontiguousarray(make_batch(1, 8, n, dup_frac=0.05)[..., :3])
+good &= bool(run('uniform dup 5%', u[:1], 64, check=1, reps=1))
+good &= bool(run('uniform dup 5%', u, 4096))
+if not quick:
+    bm = np.ascontiguousarray(beam_batch(3, 8, n)[..., :3])
+    good &= bool(run('ray-cast', bm, 4096))
+    d = u.copy(); d[:, n // 2:] = d[:, :n - n // 2]
+    good &= bool(run('every point twice', d, 4096))
+    lat = np.random.default_rng(0).integers(0, 12, (2, n, 3)).astype(np.float32)
+    good &= bool(run('lattice (exact ties)', lat, 2048))
+    good &= bool(run('all equal', np.ones((2, n, 3), np.float32), 64))
+    out = u[:2].copy(); out[0, 5] = (1e4, -1e4, 50); out[1, 100] = (-3e3, 2e3, -70)
+    good &= bool(run('outliers', out, 1024))
+    good &= bool(run('b=32', np.ascontiguousarray(make_batch(9, 32, n)[..., :3]), 4096, check=2, reps=3))
+    good &= bool(run('m=n', u[:1], n, check=1, reps=1))
+print('ALL EXACT' if good else 'MISMATCH')
+sys.exit(0 if good else 1)

@@ -1,0 +1,46 @@
+"""The look-ahead sampler's decision rule is sound under any schedule (model: tests/models/fps_lookahead.py)."""
+import numpy as np
+import pytest
+
+from tests.models import fps_lookahead as M
+
+
+def _regions(n, nreg, rng, spatial, xyz):
+    if spatial:   # compact regions along x, like the Morton regions of the kernel
+        order = np.argsort(xyz[:, 0], kind='stable')
+    else:
+        order = rng.permutation(n)
+    return np.array_split(order, nreg)
+
+
+@pytest.mark.parametrize("case", ["uniform", "lattice", "duplicates", "all_equal", "clustered"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_lookahead_model_equals_sequential_fps(case, seed):
+    rng = np.random.default_rng(100 + seed)
+    n, m, nreg = 512, 96, 8
+    if case == "uniform":
+        xyz = rng.uniform(-10, 10, (n, 3))
+    elif case == "lattice":          # exact ties everywhere
+        xyz = rng.integers(0, 6, (n, 3)).astype(np.float64)
+    elif case == "duplicates":       # the reference pads short frames with repeated points
+        base = rng.uniform(-10, 10, (n // 4, 3))
+        xyz = base[rng.integers(0, n // 4, n)]
+    elif case == "all_equal":
+        xyz = np.ones((n, 3)) * 3.25
+    else:
+        xyz = np.concatenate([rng.normal(c, 0.3, (n // 4, 3)) for c in ((0, 0, 0), (8, 0, 0), (0, 8, 0), (30, 30, 0))])
+    xyz = xyz.astype(np.float32)
+    want = M.fps_sequential(xyz, m)
+    for spatial in (True, False):
+        regs = _regions(n, nreg, rng, spatial, xyz)
+        stats = {}
+        got = M.run(xyz, m, regs, seed=seed * 7 + spatial, stats=stats)
+        assert got == want, (case, spatial)
+
+
+def test_lookahead_model_two_point_regions_and_single_region():
+    rng = np.random.default_rng(5)
+    xyz = rng.integers(0, 4, (64, 3)).astype(np.float32)
+    want = M.fps_sequential(xyz, 64)
+    assert M.run(xyz, 64, np.array_split(np.arange(64), 32), seed=3) == want     # regions of exactly two points
+    assert M.run(xyz, 64, [np.arange(64)], seed=4) == want
