@@ -98,6 +98,7 @@ _SIGNATURES = {
     "det6d_group_expand": [c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
                            _P, _P, _P, _P, c_int, _P],
     "det6d_sigmoid_pow": [c_int, _P, c_float, _P, _P],
+    "det6d_group_maxpool": [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, _P],
     "det6d_vote_points": [c_int, _P, c_int, _P, c_int, c_float, c_float, c_float, _P, c_int, _P, _P],
     "det6d_decode_boxes": [c_int, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P, _P],
     "det6d_prepare_points": [c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, c_float,
@@ -115,7 +116,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
                                                   "det6d_postprocess_workspace_bytes", "det6d_fps_fused_workspace_bytes",
                                                   "det6d_fps_fused_status_offset", "det6d_mlp_rows_supported",
-                                                  "det6d_fps_seq_timeouts",
+                                                  "det6d_fps_seq_timeouts", "det6d_ball_query_grid_supported",
                                                   "det6d_ball_query_grid_workspace_bytes",
                                                   "det6d_prepare_points_workspace_bytes",
                                                   "det6d_compact_rows_capacity", "det6d_compact_hdr_ints"])
@@ -150,6 +151,8 @@ def lib():
         handle.det6d_mlp_rows_supported.restype = c_int
         handle.det6d_fps_fused_status_offset.argtypes = [c_int, c_int, _P, c_int64]
         handle.det6d_fps_fused_status_offset.restype = c_int64
+        handle.det6d_ball_query_grid_supported.argtypes = [c_int, c_int, c_int]
+        handle.det6d_ball_query_grid_supported.restype = c_int
         handle.det6d_fps_seq_timeouts.argtypes = []
         handle.det6d_fps_seq_timeouts.restype = c_int
         handle.det6d_compact_hdr_ints.argtypes = [c_int]

@@ -12,7 +12,8 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxSample = 128;
+constexpr int kMaxSample = 128;      // fused two-shell kernel: static hit lists
+constexpr int kMaxSampleDyn = 4096;  // single-shell kernels: one dynamic-LDS hit list of nsample entries per wave (64 KB)
 
 enum { BQ_PLAIN = 0, BQ_CNT = 1, BQ_DILATED = 2 };
 
@@ -20,7 +21,7 @@ template <int MODE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ball_query_kernel(
     int n, int m, float rin2, float rout2, int nsample, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_cnt, int *__restrict__ idx) {
-  __shared__ int hits[kWavesPerBlock][kMaxSample];
+  extern __shared__ int hits[];      // [kWavesPerBlock][nsample]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int bs = blockIdx.y;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ball_query_kernel(
   const float *q = new_xyz + ((size_t)bs * m + pt) * 3;
   const float qx = q[0], qy = q[1], qz = q[2];
   const float *p = xyz + (size_t)bs * n * 3;
-  int *hb = hits[wave];
+  int *hb = hits + wave * nsample;
 
   int cnt = 0;
   for (int k0 = 0; k0 < n; k0 += 64) {
@@ -68,13 +69,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ball_query_kernel(
 template <int MODE>
 int launch(int b, int n, int m, float rin, float rout, int nsample, const float *new_xyz,
            const float *xyz, int *idx_cnt, int *idx, hipStream_t stream) {
-  if (b < 0 || n < 0 || m < 0 || nsample <= 0 || nsample > kMaxSample || !new_xyz || !xyz || !idx ||
+  if (b < 0 || n < 0 || m < 0 || nsample <= 0 || nsample > kMaxSampleDyn || !new_xyz || !xyz || !idx ||
       (MODE != BQ_PLAIN && !idx_cnt))
     return DET6D_EINVAL;
   if (b == 0 || m == 0) return DET6D_OK;
   const float rin2 = rin * rin, rout2 = rout * rout;  // fp32 products like the reference
   dim3 grid(det6d_divup(m, kWavesPerBlock), b), block(64 * kWavesPerBlock);
-  hipLaunchKernelGGL((ball_query_kernel<MODE>), grid, block, 0, stream, n, m, rin2, rout2, nsample,
+  hipLaunchKernelGGL((ball_query_kernel<MODE>), grid, block, (size_t)kWavesPerBlock * nsample * sizeof(int), stream, n, m, rin2, rout2, nsample,
                      new_xyz, xyz, idx_cnt, idx);
   return det6d_check_launch("det6d_ball_query");
 }

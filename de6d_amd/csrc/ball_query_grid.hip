@@ -239,6 +239,13 @@ __global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
 
 }  // namespace
 
+// largest scene the per-scene build kernel bins (LDS histogram of kGridCells cells, one workgroup per scene)
+constexpr int kGridMaxN = 98304;
+
+DET6D_API int det6d_ball_query_grid_supported(int n, int ns_a, int ns_b) {
+  return n > 0 && n <= kGridMaxN && ns_a > 0 && ns_b > 0 && ns_a <= kMaxNs && ns_b <= kMaxNs;
+}
+
 DET6D_API int64_t det6d_ball_query_grid_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
   const int64_t per = 32 + (int64_t)(kGridCells + 1) * 4 + (int64_t)n * 16;
@@ -249,7 +256,7 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
                                          float rout_b, int ns_b, const float *new_xyz, const float *xyz,
                                          void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
                                          det6d_stream_t stream) {
-  if (b < 0 || n <= 0 || m < 0 || ns_a <= 0 || ns_b <= 0 || ns_a > kMaxNs || ns_b > kMaxNs || !new_xyz || !xyz ||
+  if (b < 0 || m < 0 || !det6d_ball_query_grid_supported(n, ns_a, ns_b) || !new_xyz || !xyz ||
       !workspace || ((uintptr_t)workspace & 15) || !cnt_a || !idx_a || !cnt_b || !idx_b)
     return DET6D_EINVAL;
   if (b == 0 || m == 0) return DET6D_OK;

@@ -218,6 +218,20 @@ __global__ void with_batch_index_kernel(int64_t total, int m, int ld_src, int nc
   }
 }
 
+// mask + max over the ns rows of a group, one thread per (group, column): consecutive threads read consecutive columns
+__global__ void group_maxpool_kernel(int64_t total, int ns, int ncols, const float *__restrict__ x, int ldx,
+                                     const int *__restrict__ cnt, float *__restrict__ y, int ldy, int col0) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / ncols;
+    const int c = (int)(t - r * ncols);
+    const float *p = x + (size_t)r * ns * ldx + c;
+    float v = p[0];
+    for (int s = 1; s < ns; ++s) v = d6_vmax(v, p[(size_t)s * ldx]);
+    if (cnt && cnt[r] <= 0) v = 0.f;
+    y[(size_t)r * ldy + col0 + c] = v;
+  }
+}
+
 __global__ void gather_rows_kernel(int64_t total, int n, int m, int ld_in, int ld_out, int ncol,
                                    const float *__restrict__ rows_in, const int *__restrict__ idx,
                                    float *__restrict__ rows_out) {
@@ -419,6 +433,15 @@ DET6D_API int det6d_gather_rows(int b, int n, int m, int ld_in, int ld_out, int 
   hipLaunchKernelGGL(gather_rows_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, n, m, ld_in,
                      ld_out, ncol, rows_in, idx, rows_out);
   return det6d_check_launch("det6d_gather_rows");
+}
+
+DET6D_API int det6d_group_maxpool(int groups, int ns, int ncols, const float *x, int ldx, const int *cnt, float *y, int ldy,
+                                  int col0, det6d_stream_t stream) {
+  if (groups < 0 || ns <= 0 || ncols <= 0 || ncols > ldx || col0 < 0 || col0 + ncols > ldy || !x || !y) return DET6D_EINVAL;
+  const int64_t total = (int64_t)groups * ncols;
+  if (total == 0) return DET6D_OK;
+  hipLaunchKernelGGL(group_maxpool_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, ns, ncols, x, ldx, cnt, y, ldy, col0);
+  return det6d_check_launch("det6d_group_maxpool");
 }
 
 DET6D_API int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,

@@ -402,6 +402,15 @@ def postprocess(cls, boxes, b, score_thr, pre_max, post_max, nms_thr):
     return ob, os_, ol, oi, oc
 
 
+def group_maxpool(x, ns, ncols, cnt, out, col0):
+    """out[r, col0:col0+ncols] = (cnt[r] > 0) * max over the ns rows of group r of x[:, :ncols] — mask + max_pool2d for any
+    nsample (pointnet2_modules.py:465-472); the GEMM epilogues pool nsample in {8, 16, 32} themselves"""
+    L.require_cuda(x, cnt, out)
+    groups = x.shape[0] // ns
+    L.call("det6d_group_maxpool", groups, ns, ncols, L.ptr(x), x.shape[-1], L.ptr(cnt), L.ptr(out), out.shape[-1], col0,
+           L.stream_ptr())
+
+
 def nms_device(boxes, thresh, normal=False):
     """device-resident NMS: returns (keep int64 (K,), num_keep int32 (1,)) without a host sync"""
     L.require_cuda(boxes)
@@ -429,7 +438,7 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
     dev = xyz.device
     if grid is None:
         grid = GRID_QUERY_MIN_N <= n
-    if grid and max(shell_a[2], shell_b[2]) <= 64:      # the grid kernel ranks one list entry per lane
+    if grid and L.lib().det6d_ball_query_grid_supported(n, shell_a[2], shell_b[2]):   # (it ranks one list entry per lane: nsample <= 64)
         cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
         cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
         idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)
@@ -439,6 +448,15 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
                float(shell_b[0]), float(shell_b[1]), shell_b[2], L.ptr(new_xyz), L.ptr(xyz), L.ptr(ws), L.ptr(cnt_a),
                L.ptr(idx_a), L.ptr(cnt_b), L.ptr(idx_b), L.stream_ptr())
         return cnt_a, idx_a, cnt_b, idx_b
+    if max(shell_a[2], shell_b[2]) > 128:              # beyond the fused kernel's static hit lists: one query per shell
+        out = []
+        for rin, rout, ns in (shell_a, shell_b):
+            cnt = torch.zeros((b, m), dtype=torch.int32, device=dev)
+            idx = torch.zeros((b, m, ns), dtype=torch.int32, device=dev)
+            L.call("det6d_ball_query_dilated", b, n, m, float(rin), float(rout), ns, L.ptr(new_xyz), L.ptr(xyz), L.ptr(cnt),
+                   L.ptr(idx), L.stream_ptr())
+            out += [cnt, idx]
+        return tuple(out)
     cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
     cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
     idx_a = torch.empty((b, m, shell_a[2]), dtype=torch.int32, device=dev)

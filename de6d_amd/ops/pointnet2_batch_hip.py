@@ -49,8 +49,14 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
-#: from this many points on, the cnt / dilated queries go through the grid-hashed kernel
+#: from this many points on, the cnt / dilated queries go through the grid-hashed kernel — when it takes the shape
+#: (det6d_ball_query_grid_supported: nsample <= 64, n <= 98304); every other shape runs the brute-force kernels, which
+#: have no limit, like the reference's (ball_query_gpu.cu:53-130)
 GRID_QUERY_MIN_N = 2048
+
+
+def _grid_takes(n, nsample):
+    return n >= GRID_QUERY_MIN_N and bool(L.lib().det6d_ball_query_grid_supported(n, nsample, 1))
 
 
 def _grid_shell(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx):
@@ -67,7 +73,7 @@ def _grid_shell(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, 
 
 def ball_query_cnt_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx_cnt, idx):
     L.require_cuda(new_xyz, xyz, idx_cnt, idx)
-    if GRID_QUERY_MIN_N <= n <= 98304 and nsample <= 128:
+    if _grid_takes(n, nsample):
         return _grid_shell(b, n, m, 0.0, radius, nsample, new_xyz, xyz, idx_cnt, idx)
     L.call("det6d_ball_query_cnt", b, n, m, radius, nsample, L.ptr(new_xyz), L.ptr(xyz), L.ptr(idx_cnt),
            L.ptr(idx), _s())
@@ -76,11 +82,18 @@ def ball_query_cnt_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx_cnt, idx)
 
 def ball_query_dilated_wrapper(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx):
     L.require_cuda(new_xyz, xyz, idx_cnt, idx)
-    if GRID_QUERY_MIN_N <= n <= 98304 and nsample <= 128:
+    if _grid_takes(n, nsample):
         return _grid_shell(b, n, m, radius_in, radius_out, nsample, new_xyz, xyz, idx_cnt, idx)
     L.call("det6d_ball_query_dilated", b, n, m, radius_in, radius_out, nsample, L.ptr(new_xyz), L.ptr(xyz),
            L.ptr(idx_cnt), L.ptr(idx), _s())
     return 1
+
+
+def grid_query_wrapper(out_nebidx, out_nebidxmsk, out_cent, out_centmsk, out_actual_centnum, in_data, in_actual_numpoints,
+                       param_coord_shift, param_grid_size, param_voxel_size, param_kernel_size):
+    raise NotImplementedError(
+        "grid_query_wrapper (gridify.h:13-25) is exported by the reference's module but called by nothing on the Det6D path "
+        "(SURVEY.md 8b: dead); libdet6d_hip does not provide it")
 
 
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):

@@ -341,8 +341,8 @@ class _PointnetSAModuleFSBase(nn.Module):
                 else:
                     fused.linear(x, w, shift, act, tgt, **kw)
                 x = tgt
-                if last and not poolable:  # generic nsample: mask + max in torch-free HIP is not
-                    raise NotImplementedError("fused max-pool supports nsample in {8,16,32}")
+                if last and not poolable:  # any other nsample: the layer is written out, mask + max in their own launch
+                    fused.group_maxpool(x, nsample, cout, idx_cnt, pooled, col)
             col += layers[-1][2]
         new_scores = None
         if f['agg'] is not None:

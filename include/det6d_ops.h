@@ -64,7 +64,9 @@ int det6d_gather_points_grad(int b, int c, int n, int npoints, const float *grad
 /* ------------------------------------------------------------------ ball query ----------- */
 
 /* Replaces ball_query_wrapper (ball_query_gpu.cu:15-51,157-176).
- *   new_xyz (B,M,3); xyz (B,N,3); idx (B,M,nsample) i32, caller zero-fills. */
+ *   new_xyz (B,M,3); xyz (B,N,3); idx (B,M,nsample) i32, caller zero-fills.
+ * The three single-shell entries take nsample <= 4096 (one LDS hit list per wave; the reference has no cap, nobody
+ * configures more than 128); det6d_ball_query_pair and the grid form are narrower: see there. */
 int det6d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                      const float *xyz, int *idx, det6d_stream_t stream);
 
@@ -80,7 +82,8 @@ int det6d_ball_query_dilated(int b, int n, int m, float radius_in, float radius_
 /* Fused form of two cnt/dilated queries over the same (new_xyz, xyz): shell A accepts
  * rin_a^2 <= d2 < rout_a^2 (rin = 0: plain ball), shell B likewise; results are identical to two
  * separate det6d_ball_query_dilated / _cnt calls on zero-filled idx buffers (empty balls are
- * written as zeros here, so no memset is needed).  One sweep over the points feeds both groups of an
+ * written as zeros here, so no memset is needed).  ns_a, ns_b <= 128 (DET6D_EINVAL beyond: two single-shell calls).
+ * One sweep over the points feeds both groups of an
  * SA layer (pointnet2_modules.py:462-463 loops the groupers over the same inputs). */
 int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
                           float rout_b, int ns_b, const float *new_xyz, const float *xyz, int *cnt_a,
@@ -91,7 +94,10 @@ int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns
  * 3x3 cell neighbourhood and keeps, per shell, the nsample smallest hit indices (a short LDS list with a
  * pruning threshold, ranked once at the end: the reference's ascending-index order).  workspace:
  * det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.  ns_a, ns_b <= 64
- * (DET6D_EINVAL beyond: use det6d_ball_query_pair). */
+ * (DET6D_EINVAL beyond: use det6d_ball_query_pair).  det6d_ball_query_grid_supported(n, ns_a, ns_b): 1 when this entry takes
+ * the shape (the host asks before it routes a query here instead of through det6d_ball_query_pair / _cnt / _dilated, which
+ * have no nsample limit, like the reference: ball_query_gpu.cu:53-130). */
+int det6d_ball_query_grid_supported(int n, int ns_a, int ns_b);
 int64_t det6d_ball_query_grid_workspace_bytes(int b, int n);
 int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
                                float rout_b, int ns_b, const float *new_xyz, const float *xyz,
@@ -458,6 +464,13 @@ int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *crow_p, co
                              int lda, const float *ctr, int ldctr, const float *w1, int ldw1, const float *s1, int c1,
                              const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
                              const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream);
+
+/* Mask + max-pool of a grouped MLP's last layer for ANY nsample (pointnet2_modules.py:465-472: new_features *= (idx_cnt > 0);
+ * F.max_pool2d(kernel_size=[1, nsample])):  y[r*ldy + col0 + c] = cnt[r] > 0 ? max_s x[(r*ns + s)*ldx + c] : 0  for r < groups,
+ * c < ncols (cnt == NULL: no mask).  The fused GEMM epilogues pool nsample in {8, 16, 32} themselves; this entry is the
+ * fallback for every other nsample. */
+int det6d_group_maxpool(int groups, int ns, int ncols, const float *x, int ldx, const int *cnt, float *y, int ldy, int col0,
+                        det6d_stream_t stream);
 
 /* s-fps weights: w[i] = sigmoid(score[i]) ** gamma  (pointnet2_modules.py:415-419) */
 int det6d_sigmoid_pow(int count, const float *scores, float gamma, float *weights,

@@ -865,6 +865,20 @@ ORACLE_API int det6d_oracle_mlp_chain3_compact(int capacity, const int *hdr, con
   return rc;
 }
 
+/* pointnet2_modules.py:465-472: new_features *= (idx_cnt > 0); F.max_pool2d(kernel_size=[1, nsample]) — any nsample */
+ORACLE_API int det6d_oracle_group_maxpool(int groups, int ns, int ncols, const float *x, int ldx, const int *cnt, float *y,
+                                          int ldy, int col0) {
+  if (groups < 0 || ns <= 0 || ncols <= 0) return -1;
+  for (int r = 0; r < groups; ++r)
+    for (int c = 0; c < ncols; ++c) {
+      const float mask = (!cnt || cnt[r] > 0) ? 1.0f : 0.0f;
+      float v = x[((size_t)r * ns) * ldx + c] * mask;
+      for (int s = 1; s < ns; ++s) v = d6_fmaxf(v, x[((size_t)r * ns + s) * ldx + c] * mask);
+      y[(size_t)r * ldy + col0 + c] = v;
+    }
+  return 0;
+}
+
 /* pointnet2_modules.py:415-419 */
 ORACLE_API int det6d_oracle_sigmoid_pow(int count, const float *scores, float gamma, float *weights) {
   for (int i = 0; i < count; ++i) weights[i] = d6_sigmoid_powf(scores[i], gamma);

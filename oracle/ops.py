@@ -322,6 +322,18 @@ def linear(a, w, shift=None, act=0, k=None, idx=None, ctr=None, cnt=None, pool=0
     return out
 
 
+def group_maxpool(x, ns, ncols, cnt=None):
+    """(groups * ns, ldx) rows -> (groups, ncols): mask by cnt > 0, then max over the ns rows of a group"""
+    x = _f(x)
+    groups = x.shape[0] // ns
+    y = np.zeros((groups, ncols), np.float32)
+    c = _i(cnt).reshape(-1) if cnt is not None else None
+    rc = lib().det6d_oracle_group_maxpool(groups, ns, ncols, _pf(x), x.shape[1], _pi(c) if c is not None else None, _pf(y),
+                                          ncols, 0)
+    assert rc == 0
+    return y
+
+
 def sigmoid_pow(scores, gamma=1.0):
     s = _f(scores)
     out = np.empty_like(s)

@@ -22,6 +22,7 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    eval.py (both copies) executed as plain Python (numba.jit stubbed to the identity; the
                    numba.cuda launch of rotate_iou_gpu_eval replaced by a loop over the reference's own
                    devRotateIoUEval device function)
+  extension_api.json  names + positional arities of the reference's two pybind modules (parsed from its *_api.cpp and headers)
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -637,10 +638,70 @@ def gen_eval():
     print("kitti_eval.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- extension API
+def gen_extension_api():
+    """extension_api.json: what the reference's two pybind modules export — python name -> positional arity — parsed from
+    pointnet2_api.cpp:11-30 / iou3d_nms_api.cpp:11-17 (the m.def lines) and the C++ prototypes they bind
+    (sampling_gpu.h:9-39, ball_query_gpu.h:9-25, group_points_gpu.h, interpolate_gpu.h, gridify.h, iou3d_nms.h:9-12,
+    iou3d_cpu.h).  tests/test_boundary.py holds de6d_amd's drop-in modules to exactly these names and arities."""
+    import json
+    import re
+
+    def strip_comments(text):
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        return re.sub(r'//[^\n]*', '', text)
+
+    def prototypes(paths):
+        protos = {}
+        for path in paths:
+            text = strip_comments(open(path).read())
+            for ret, name, args in re.findall(r'\b(int|void)\s+(\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+                args = args.strip()
+                # split on top-level commas (std::vector<float> has none inside, but stay general)
+                depth, parts, cur = 0, [], ''
+                for ch in args:
+                    depth += ch == '<'
+                    depth -= ch == '>'
+                    if ch == ',' and depth == 0:
+                        parts.append(cur); cur = ''
+                    else:
+                        cur += ch
+                if cur.strip():
+                    parts.append(cur)
+                protos[name] = dict(returns=ret, arity=len(parts), args=[' '.join(a.split()) for a in parts])
+        return protos
+
+    def module(api_cpp, headers):
+        protos = prototypes(headers)
+        out = {}
+        for pyname, cname in re.findall(r'm\.def\(\s*"(\w+)"\s*,\s*&(\w+)', strip_comments(open(api_cpp).read())):
+            out[pyname] = dict(binds=cname, **protos[cname])
+        return out
+
+    pn = os.path.join(REF, 'pcdet/ops/pointnet2/pointnet2_batch/src')
+    iou = os.path.join(REF, 'pcdet/ops/iou3d_nms/src')
+    api = {
+        'pointnet2_batch_cuda': module(os.path.join(pn, 'pointnet2_api.cpp'),
+                                       [os.path.join(pn, h) for h in ('sampling_gpu.h', 'ball_query_gpu.h', 'group_points_gpu.h',
+                                                                      'interpolate_gpu.h', 'gridify.h')]),
+        'iou3d_nms_cuda': module(os.path.join(iou, 'iou3d_nms_api.cpp'), [os.path.join(iou, h) for h in ('iou3d_nms.h', 'iou3d_cpu.h')]),
+        'import_sites': {
+            'pointnet2_batch_cuda': 'pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda',   # pointnet2_utils.py:7
+            'iou3d_nms_cuda': 'pcdet.ops.iou3d_nms.iou3d_nms_cuda',                              # iou3d_nms_utils.py:9
+        },
+    }
+    with open(os.path.join(HERE, 'extension_api.json'), 'w') as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print('extension_api.json', {k: len(v) for k, v in api.items()})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ['extension_api']:          # needs neither the oracle nor oracle/_ref
+        gen_extension_api()
+        sys.exit(0)
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
     gens = dict(nms=gen_nms, box_coder=gen_box_coder, model=gen_model, producer=gen_producer, annos=gen_annos,
-                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, fp=gen_fp)
+                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, fp=gen_fp, extension_api=gen_extension_api)
     for name in (sys.argv[1:] or list(gens)):      # `python make_golden.py model_full` regenerates one fixture
         gens[name]()
