@@ -233,6 +233,26 @@ __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log
   return cmax;
 }
 
+// min-distances of this wave's points against one more pick; no arg-max bookkeeping (a later sq_rescan of the same batch does
+// it once for all the picks)
+template <int SG>
+__device__ __forceinline__ void sq_apply(float cx, float cy, float cz, const float (&px)[SG], const float (&py)[SG],
+                                         const float (&pz)[SG], float (&pt)[SG]) {
+  const sq_f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+  for (int q = 0; q < SG / 2; ++q) {
+    const int s0 = 2 * q;
+    const sq_f32x2 dx = sq_f32x2{px[s0], px[s0 + 1]} - c2x;
+    const sq_f32x2 dy = sq_f32x2{py[s0], py[s0 + 1]} - c2y;
+    const sq_f32x2 dz = sq_f32x2{pz[s0], pz[s0 + 1]} - c2z;
+    sq_f32x2 d = dy * dy;
+    d = __builtin_elementwise_fma(dx, dx, d);
+    d = __builtin_elementwise_fma(dz, dz, d);
+    pt[s0] = d6_vmin(d[0], pt[s0]);
+    pt[s0 + 1] = d6_vmin(d[1], pt[s0 + 1]);
+  }
+}
+
 __device__ int d6_fps_seq_timeouts;
 
 #ifdef DET6D_EXPERIMENTS
@@ -250,7 +270,7 @@ constexpr int kIdleLimit = 1 << 21;
 
 __device__ __forceinline__ void sq_owner(int ow, int n, int m, int log2s, const float *__restrict__ xyz, const int *__restrict__ perm,
                                          unsigned short *korig, u64 *rec, const u64 *hist, int *progress,
-                                         unsigned long long *sq_stats_lds) {
+                                         unsigned long long *sq_stats_lds, int tune_sleep) {
   constexpr int SG = kSlots;
   const int lane = threadIdx.x & 63;
   unsigned short *korig_w = korig + (size_t)ow * kOwnerPoints;
@@ -306,7 +326,9 @@ __device__ __forceinline__ void sq_owner(int ow, int n, int m, int log2s, const 
     // has the next pick been made?  (one broadcast read: 15 owners polling 64 entries each would take half the LDS bandwidth)
     if ((unsigned)(sq_ld(hist + (r_next & (kRing - 1)) * 3 + 2) >> 32) != (unsigned)r_next + 1u) {
       if (ow == 4) SQ_STAT(12, 1);
-      __builtin_amdgcn_s_sleep(1);
+      // sleep until the sequencer's next s_wakeup (or ~2000 cycles, if the ping fell between the test and the sleep): a
+      // polling owner must not take issue slots from the rescans and the sequencer on its SIMD
+      for (int i = 0; i < tune_sleep; ++i) __builtin_amdgcn_s_sleep(8);
       continue;
     }
     // the next 64 picks at once
@@ -325,16 +347,23 @@ __device__ __forceinline__ void sq_owner(int ow, int n, int m, int log2s, const 
     const float gy = fmaxf(0.f, fmaxf(loy - sy, sy - hiy));
     const float gz = fmaxf(0.f, fmaxf(loz - sz, sz - hiz));
     const float lb = d6_sqdist(gx, gy, gz);
-    const u64 need = __ballot(!(lb >= cmax));
-    const int first = need == 0ull ? 64 : __builtin_ctzll(need);
-    const int nskip = first < nvalid ? first : nvalid;
-    r_next += nskip;
-    if (nskip < nvalid) {                                   // pick r_next can change this wave's points
-      const float cx = d6_readlane_f(sx, nskip), cy = d6_readlane_f(sy, nskip), cz = d6_readlane_f(sz, nskip);
-      r_next += 1;
+    // picks of the batch that can change this wave's points (tested against the maximum BEFORE the batch: min-distances only
+    // decrease, so the test stays conservative for the later ones)
+    u64 need = __ballot(!(lb >= cmax)) & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
+    r_next += nvalid;                                       // the whole batch is applied below: picks that fail the test change nothing
+    if (need != 0ull) {
+      // all of them in one go: plain min passes for all but the last, then ONE pass that also tracks the arg-max and
+      // publishes the record — an owner that fell behind catches up at the price of one extraction
+      while (need & (need - 1ull)) {
+        const int i = __builtin_ctzll(need);
+        need &= need - 1ull;
+        sq_apply<SG>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), px, py, pz, pt);
+        if (ow == 4) SQ_STAT(15, 1);
+      }
+      const int i = __builtin_ctzll(need);
       if (ow == 4) SQ_STAT(13, 1);
       SQ_STAT(7, 1);
-      cmax = sq_rescan<SG>(cx, cy, cz, log2s, px, py, pz, pt, korig_w, rec, r_next);
+      cmax = sq_rescan<SG>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, r_next);
     }
     if (lane == 0) __hip_atomic_store(&progress[ow], r_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -342,7 +371,7 @@ __device__ __forceinline__ void sq_owner(int ow, int n, int m, int log2s, const 
 
 // Lane 4j + s = candidate s of region j.
 __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int *__restrict__ idxs, const u64 *rec, u64 *hist,
-                                             const int *progress, unsigned long long *sq_stats_lds) {
+                                             const int *progress, unsigned long long *sq_stats_lds, int tune_wake) {
   const int lane = threadIdx.x & 63;
   const bool live = lane < kOwners * kCand;
   const int slot = lane & 3;
@@ -371,6 +400,7 @@ __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int 
       return;
     }
     SQ_STAT(0, 1);
+    const long long tq0 = SQ_CLK();
     // -- 1. new records?  (the owner writes the bound word last)
     const u64 wb = sq_ld(rp + kWordBound);
     const unsigned t0 = (unsigned)(wb >> 32);
@@ -418,6 +448,8 @@ __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int 
         }
       }
     }
+    const long long tq1 = SQ_CLK();
+    SQ_STAT(8, tq1 - tq0);
     // -- 2. decide
     if (r_dec - minprog >= kRing - 64) {                   // the ring slot about to be overwritten may still be unread
       const float p = lane < kOwners ? (float)__hip_atomic_load(&progress[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 3.0e38f;
@@ -435,7 +467,7 @@ __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int 
     const float ub = live && !exact ? bound_v : -1.0f;
     float E, UB;
     sq_wave_max2(ev, ub, E, UB);
-    if (!(UB < E)) { SQ_STAT(2, 1); continue; }            // some region's maximum is unknown and may be the largest: poll
+    if (!(UB < E)) { SQ_STAT(2, 1); SQ_STAT(10, SQ_CLK() - tq1); continue; }   // some region's maximum is unknown and may be the largest: poll
     const u64 tie = __ballot(ev == E);
     int wl = __builtin_ctzll(tie);
     if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, sq_tie_key(kidx, log2s));
@@ -443,11 +475,13 @@ __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int 
     const int k = d6_readlane_i(kidx, wl);
     if (lane < 3) sq_st(hist + (r_dec & (kRing - 1)) * 3 + lane, sq_pack(sq_fbits(lane == 0 ? sx : lane == 1 ? sy : sz), (unsigned)r_dec + 1u));
     if (lane == 0) idxs[r_dec] = k + idx_add;
+    if (tune_wake) asm volatile("s_wakeup");               // owners asleep in their poll loop look at the ring now
     sq_writelane3(hx, hy, hz, sx, sy, sz, r_dec & 63);
     cv = d6_vmin(cv, d6_sqdist(qx - sx, qy - sy, qz - sz));   // (an empty slot stays at -1)
     ++r_dec;
     idle = 0;
     SQ_STAT(1, 1);
+    SQ_STAT(9, SQ_CLK() - tq1);
   }
 #ifdef DET6D_EXPERIMENTS
   SQ_STAT(11, clock64() - t_begin);
@@ -459,7 +493,8 @@ __device__ __forceinline__ void sq_sequencer(int m, int log2s, int idx_add, int 
 // One workgroup of 16 waves per scene.  `perm`: the scene's Morton permutation (n entries).
 __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
                                                        int idx_add, const float *__restrict__ xyz,
-                                                       const int *__restrict__ perm, int *__restrict__ idxs) {
+                                                       const int *__restrict__ perm, int *__restrict__ idxs, int tune_sleep,
+                                                       int tune_wake) {
   __shared__ unsigned short korig[kOwners * kOwnerPoints];   // sorted slot -> original index
   __shared__ u64 rec[kOwners * kRecStride];
   __shared__ u64 hist[kRing * 3];
@@ -485,10 +520,10 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
   if (h == 0) idxs[0] = idx_add;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    sq_sequencer(m, log2s, idx_add, idxs, rec, hist, progress, sq_stats);
+    sq_sequencer(m, log2s, idx_add, idxs, rec, hist, progress, sq_stats, tune_wake);
     return;
   }
-  sq_owner(wave - 1, n, m, log2s, xyz, perm, korig, rec, hist, progress, sq_stats);
+  sq_owner(wave - 1, n, m, log2s, xyz, perm, korig, rec, hist, progress, sq_stats, tune_sleep);
 }
 
 }  // namespace
@@ -514,6 +549,9 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, l
                          int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream) {
   if (n != 16384) return DET6D_EINVAL;
   (void)regions_per_wave;
-  hipLaunchKernelGGL(fps_seq_kernel, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx);
+  static const int tune_sleep = det6d_env_int("DET6D_FPS_SEQ_SLEEP", 4);   // x 512 cycles
+  static const int tune_wake = det6d_env_int("DET6D_FPS_SEQ_WAKE", 1);
+  hipLaunchKernelGGL(fps_seq_kernel, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx,
+                     tune_sleep, tune_wake);
   return det6d_check_launch("det6d_fps (look-ahead)");
 }

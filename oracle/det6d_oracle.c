@@ -28,7 +28,15 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* The reference writes dx*dx + dy*dy + dz*dz (sampling_gpu.cu:143, ball_query_gpu.cu:39, interpolate_gpu.cu:37) and lets
+ * NVCC contract it.  Two contractions are plausible: the one LLVM's DAG combiner emits — fma(dz,dz, fma(dx,dx, dy*dy)), the
+ * shipped convention — and SURVEY.md A.2's left-to-right reading fma(dz,dz, fma(dy,dy, dx*dx)).  No NVIDIA toolchain is
+ * available to settle it, so the alternative can be switched on (tests/test_contraction_order.py quantifies what it would
+ * change; nothing else ever sets it). */
+static int g_sqdist_alt = 0;
+ORACLE_API void det6d_oracle_set_sqdist_order(int alt) { g_sqdist_alt = alt; }
 static inline float sqdist(float dx, float dy, float dz) {
+  if (g_sqdist_alt) return D6_FMA(dz, dz, D6_FMA(dy, dy, dx * dx));
   return D6_FMA(dz, dz, D6_FMA(dx, dx, dy * dy));
 }
 

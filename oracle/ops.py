@@ -59,6 +59,12 @@ def opt_n_threads(n):
     return int(lib().det6d_oracle_opt_n_threads(_c_int(n)))
 
 
+def set_sqdist_order(alt):
+    """0: the shipped contraction fma(dz,dz, fma(dx,dx, dy*dy)); 1: SURVEY.md A.2's fma(dz,dz, fma(dy,dy, dx*dx)) — every
+    squared distance of the oracle (FPS, ball queries, 3-NN) follows.  Only tests/test_contraction_order.py uses 1."""
+    lib().det6d_oracle_set_sqdist_order(int(bool(alt)))
+
+
 def fps(xyz, m, temp=None):
     xyz = _f(xyz)
     b, n, _ = xyz.shape

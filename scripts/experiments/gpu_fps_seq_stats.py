@@ -6,8 +6,8 @@ from de6d_amd import _lib as L
 from de6d_amd.ops import fused
 from tests.util import make_batch, beam_batch
 names = ['seq steps', 'decisions', 'blocked', 'ring breaks', 'polls w/ new rec', 'picks replayed', 'records accepted',
-         'rescans (all)', 'cyc poll/accept', 'cyc decide', '-', 'cyc total', 'o4 empty polls', 'o4 rescans',
-         'o4 owner steps', '-']
+         'rescans (all)', 'cyc poll/accept', 'cyc decide', 'cyc blocked try', 'cyc total', 'o4 empty polls', 'o4 rescans',
+         'o4 owner steps', 'o4 extra applies']
 n, m = 16384, int(os.environ.get('M', 4096))
 b = int(os.environ.get('B', 1))
 xyz = (beam_batch(3, b, n) if 'beam' in sys.argv else make_batch(1, b, n, dup_frac=0.05))[..., :3]
