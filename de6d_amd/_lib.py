@@ -116,7 +116,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_error", "det6d_nms_mask_words",
                                                   "det6d_postprocess_workspace_bytes", "det6d_fps_fused_workspace_bytes",
                                                   "det6d_fps_fused_status_offset", "det6d_mlp_rows_supported",
-                                                  "det6d_fps_seq_timeouts", "det6d_ball_query_grid_supported",
+                                                  "det6d_ball_query_grid_supported",
                                                   "det6d_ball_query_grid_workspace_bytes",
                                                   "det6d_prepare_points_workspace_bytes",
                                                   "det6d_compact_rows_capacity", "det6d_compact_hdr_ints"])
@@ -153,8 +153,6 @@ def lib():
         handle.det6d_fps_fused_status_offset.restype = c_int64
         handle.det6d_ball_query_grid_supported.argtypes = [c_int, c_int, c_int]
         handle.det6d_ball_query_grid_supported.restype = c_int
-        handle.det6d_fps_seq_timeouts.argtypes = []
-        handle.det6d_fps_seq_timeouts.restype = c_int
         handle.det6d_compact_hdr_ints.argtypes = [c_int]
         handle.det6d_compact_hdr_ints.restype = c_int
         handle.det6d_compact_rows_capacity.argtypes = [c_int, c_int]

@@ -52,8 +52,8 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pre-pass: Morton order of a scene.  perm[b, p] = original index of the point at sorted position p.
-// Any permutation is CORRECT for the sampler below; the Morton order only makes cells compact.
+// Pre-pass: spatial order of a scene.  perm[b, p] = original index of the point at sorted position p.
+// Any permutation is CORRECT for the samplers below; the order only makes their regions compact.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned part1by1(unsigned v) {
   v &= 0xFFFFu;
@@ -91,21 +91,33 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bs
     xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
     ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
   }
-  // 10 bits per axis (7 cm cells on a KITTI scene): 20-bit keys = 5 radix passes instead of 8
-  const float sx = xmax > xmin ? 1023.0f / (xmax - xmin) : 0.f;
-  const float sy = ymax > ymin ? 1023.0f / (ymax - ymin) : 0.f;
+  // A 4 x 4 k-d grid of equal counts: sort by x, cut into 4 strips, sort every strip by y, cut into 4: region g = sorted
+  // positions [g n/16, (g+1) n/16).  A wave of the samplers below owns one region (n = 16384), and its bounding box is a
+  // tight rectangle: a new sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into
+  // 16 equal runs gives 2.65: a run that crosses a quadrant boundary of the curve has a box that spans both quadrants.
+  const float sx = xmax > xmin ? 1048575.0f / (xmax - xmin) : 0.f;
+  const float sy = ymax > ymin ? 1048575.0f / (ymax - ymin) : 0.f;
   unsigned key[IPT];
   int val[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
-    float fx = (x[i] - xmin) * sx, fy = (y[i] - ymin) * sy;
-    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1023.f) : 0.f;
-    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 1023.f) : 0.f;
-    key[i] = (part1by1((unsigned)fx) << 1) | part1by1((unsigned)fy);
+    float fx = (x[i] - xmin) * sx;
+    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1048575.f) : 0.f;
+    key[i] = (unsigned)fx;
     val[i] = tid * IPT + i;
   }
   __syncthreads();
   Sort(sort_tmp).Sort(key, val, 0, 20);
+  // sorted position p = tid * IPT + i now holds point val[i]; its strip is p / (n / 4)
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const float yy = xyz[(size_t)val[i] * 3 + 1];
+    float fy = (yy - ymin) * sy;
+    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 1048575.f) : 0.f;
+    key[i] = ((unsigned)((tid * IPT + i) / (n / 4)) << 20) | (unsigned)fy;
+  }
+  __syncthreads();
+  Sort(sort_tmp).Sort(key, val, 0, 22);
 #pragma unroll
   for (int i = 0; i < IPT; ++i) perm[tid * IPT + i] = val[i];
 }
@@ -447,11 +459,12 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
   // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
   static const int skip = det6d_switch_int("DET6D_FPS_SKIP", 16);
-  // DET6D_FPS_SEQ: regions per owner wave of the look-ahead sampler (fps_seq.hip; 1, 2 or 3), 0 = the wave-skip sampler below
-  static const int seq = det6d_switch_int("DET6D_FPS_SEQ", 2);
+  // DET6D_FPS_SEQ=0: the wave-skip sampler below instead of the multi-pick sampler (fps_seq.hip)
+  static const int seq = det6d_switch_int("DET6D_FPS_SEQ", 1);
   if (seq && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    return det6d_fps_seq_launch(b, n, m, log2s, seq >= 1 && seq <= 3 ? seq : 2, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
+    hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+    return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
   }
   if (skip && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);

@@ -299,11 +299,6 @@ long long det6d_fps_fused_workspace_bytes(int b, int n);
  * the time-out (de6d_amd/runtime.py: ScenePipeline keeps them on few enough streams). */
 int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream);
 long long det6d_fps_fused_status_offset(int b, int n, const float *temp, long long temp_bytes);
-/* The look-ahead sampler of 16384-point scenes (csrc/fps_seq.hip) has a watchdog instead of a way to hang: a workgroup whose
- * waves make no progress for seconds completes its index list with in-range placeholders and counts itself here.
- * Returns the number of such workgroups since the library was loaded (0 in a healthy process; -1: the read failed).
- * Synchronises the device. */
-int det6d_fps_seq_timeouts(void);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,
                     float gamma, float *temp, long long temp_bytes, int *idx, int idx_stride, int idx_offset,
                     int idx_bias, det6d_stream_t stream);   /* idx_bias: added to every written index on top of lo */

@@ -67,7 +67,7 @@ def test_code_object_is_gfx950_only(hip_lib):
 def test_oracle_exports_mirror_the_abi(oracle_ops):
     lib = oracle_ops.lib()
     for name in declared_symbols():
-        if name in ('det6d_version', 'det6d_last_error', 'det6d_nms_to_host', 'det6d_boxes_iou_bev_cpu', 'det6d_fps_fused_workspace_bytes', 'det6d_fps_fused_status', 'det6d_fps_fused_status_offset', 'det6d_mlp_group3_supported', 'det6d_mlp_rows_supported', 'det6d_fps_seq_timeouts',
+        if name in ('det6d_version', 'det6d_last_error', 'det6d_nms_to_host', 'det6d_boxes_iou_bev_cpu', 'det6d_fps_fused_workspace_bytes', 'det6d_fps_fused_status', 'det6d_fps_fused_status_offset', 'det6d_mlp_group3_supported', 'det6d_mlp_rows_supported',
                     'det6d_ball_query_grid_supported'):
             continue
         assert hasattr(lib, name.replace('det6d_', 'det6d_oracle_', 1)), name
