@@ -8,7 +8,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdet6d_hip.so")
-SOURCES = ["runtime.hip", "fps.hip", "fps_cells.hip", "fps_coop.hip", "fps_seq.hip", "ball_query.hip", "ball_query_grid.hip", "points.hip", "iou3d_nms.hip", "iou3d_host.hip", "linear.hip", "mlp_chain.hip", "mlp_group.hip", "mlp_rows.hip", "compact.hip", "expand.hip", "prepare.hip", "annos.hip", "slope.hip", "kitti_eval.hip"]
+SOURCES = ["runtime.hip", "fps.hip", "fps_cells.hip", "fps_coop.hip", "ball_query.hip", "ball_query_grid.hip", "points.hip", "iou3d_nms.hip", "iou3d_host.hip", "linear.hip", "mlp_chain.hip", "mlp_group.hip", "mlp_rows.hip", "compact.hip", "expand.hip", "prepare.hip", "annos.hip", "slope.hip", "kitti_eval.hip"]
+#: kernels that exist only in the -DDET6D_EXPERIMENTS library (measured alternatives that did not earn their place)
+EXPERIMENT_SOURCES = ["fps_seq.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"),
            os.path.join(HERE, "..", "include", "det6d_ops.h"),
            os.path.join(HERE, "..", "include", "det6d_math.h"),
@@ -46,6 +48,8 @@ def build(force=False, verbose=False, experiments=False):
     flags = FLAGS + (["-DDET6D_EXPERIMENTS"] if experiments else [])
     lib = LIB.replace(".so", "_experiments.so") if experiments else LIB
 
+    sources = SOURCES + (EXPERIMENT_SOURCES if experiments else [])
+
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -56,8 +60,8 @@ def build(force=False, verbose=False, experiments=False):
             subprocess.check_call(cmd)
         return o
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(6, len(sources))) as ex:
+        objs = list(ex.map(compile_one, sources))
     if force or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:

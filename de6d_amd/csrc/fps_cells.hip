@@ -446,7 +446,7 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsign
 }
 #endif
 
-// fps_seq.hip: the look-ahead sampler (sequencer wave + asynchronous region owners)
+// fps_seq.hip (experiments build only): the multi-pick sampler
 int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, long long xyz_bstride, long long idx_bstride,
                          int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream);
 
@@ -459,13 +459,17 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
   // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
   static const int skip = det6d_switch_int("DET6D_FPS_SKIP", 16);
-  // DET6D_FPS_SEQ=0: the wave-skip sampler below instead of the multi-pick sampler (fps_seq.hip)
-  static const int seq = det6d_switch_int("DET6D_FPS_SEQ", 1);
+#ifdef DET6D_EXPERIMENTS
+  // experiments build only, DET6D_FPS_SEQ=1: the multi-pick sampler (fps_seq.hip: several picks per barrier round from
+  // published top-4 lists; exact; 0.73-0.78 us per pick stand-alone against 0.83-0.85, no gain in the pipeline, 2.7x slower
+  // on clouds made of duplicated points: LABNOTES.md, round 4)
+  static const int seq = det6d_env_int("DET6D_FPS_SEQ", 0);
   if (seq && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
     hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
     return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
   }
+#endif
   if (skip && n == 16384 && init_temp) {
     hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
     // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two

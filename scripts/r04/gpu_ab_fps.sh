@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B in the pipeline: multi-pick sampler (DET6D_FPS_SEQ=1, default) vs the wave-skip sampler (=0), both on the k-d sort
+# same-box A/B in the pipeline: multi-pick sampler (experiments build, DET6D_FPS_SEQ=1) vs the shipped wave-skip sampler, both on the k-d sort
 cd $GRAFT_REPO_ROOT; export GPU_MAX_HW_QUEUES=24
 mkdir -p gpurun_out/r04
 show='import sys,json
@@ -8,8 +8,8 @@ for l in sys.stdin:
         d=json.loads(l); print(sys.argv[1], d["value"], d["config"]["window_ms_min_median_max"], "cold", d["cold"]["scenes_per_s"], "lat", d.get("latency_ms_per_batch"), d["selfcheck"])'
 B="--no-legs --cpu-scenes 0 --no-roofline --steps 20 --warmup 5"
 for i in 1 2; do
-python3 bench.py $B 2>/dev/null | python3 -c "$show" "uniform seq"
-DET6D_FPS_SEQ=0 python3 bench.py $B 2>/dev/null | python3 -c "$show" "uniform skip"
-python3 bench.py $B --scene beam 2>/dev/null | python3 -c "$show" "beam seq"
-DET6D_FPS_SEQ=0 python3 bench.py $B --scene beam 2>/dev/null | python3 -c "$show" "beam skip"
+DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=1 python3 bench.py $B 2>/dev/null | python3 -c "$show" "uniform seq"
+python3 bench.py $B 2>/dev/null | python3 -c "$show" "uniform skip"
+DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=1 python3 bench.py $B --scene beam 2>/dev/null | python3 -c "$show" "beam seq"
+python3 bench.py $B --scene beam 2>/dev/null | python3 -c "$show" "beam skip"
 done 2>&1 | tee gpurun_out/r04/ab_fps.log

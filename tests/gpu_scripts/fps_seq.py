@@ -1,5 +1,6 @@
-"""Look-ahead sampler (csrc/fps_seq.hip) against the oracle + timing; run once per DET6D_FPS_SEQ value (the switch is read
-once per process): python tests/gpu_scripts/fps_seq.py [quick]"""
+"""16384-point D-FPS against the oracle + timing, on uniform / ray-cast / duplicated / lattice / all-equal / outlier clouds.
+DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=1 selects the multi-pick sampler of the experiments build (csrc/fps_seq.hip); the
+shipped library always runs the wave-skip sampler.  python tests/gpu_scripts/fps_seq.py [quick]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
