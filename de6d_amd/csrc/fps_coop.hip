@@ -19,6 +19,12 @@
 //   written round r and is done reading round r-1.  The area is zeroed by the key kernel of the same launch (stream
 //   order), tags are round numbers >= 1.
 // Placement: block ids of one scene are congruent mod 8, i.e. on one XCD under round-robin dispatch (speed only).
+// Publishing stores are AGENT scope (the HIP memory model's guarantee that another workgroup's agent-scope load sees them).
+// DET6D_FPS_COOP_FAST=1 allows a part to publish with workgroup-scope stores — they stay in the XCD's L2 instead of being
+// written through to the fabric: 1.63 -> 1.40 us per round — when (a) all parts of its scene report the same HW_REG_XCC_ID
+// and (b) a handshake in round 0 has shown, on this device and this placement, that a workgroup-scope store of every part
+// reaches the other parts' agent-scope loads; a part that fails either test keeps agent scope (mixing is fine: readers
+// always load with agent scope).
 // A part that waits longer than ~2 s for a partner (it can only be a scheduling accident) raises the error word of
 // the workspace and leaves: det6d_fps_fused_status reports the launch as failed instead of the GPU hanging.
 #include "common.h"
@@ -134,7 +140,7 @@ template <int PARTS>
 __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int log2s, long long xyz_bstride,
                                                         long long idx_bstride, int idx_add, const float *__restrict__ xyz,
                                                         const unsigned *__restrict__ perm, int *__restrict__ idxs,
-                                                        unsigned long long *__restrict__ exch, int *err, int force_agent) {
+                                                        unsigned long long *__restrict__ exch, int *err, int allow_fast) {
   constexpr int NW = 16, SLOTS = 16, HG = SLOTS / 2;
   __shared__ float4 slot_v[2][NW];
   __shared__ int slot_k[2][NW];
@@ -177,10 +183,10 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];      // the first pick is point 0 (sampling_gpu.cu:131-133)
   if (part == 0 && h == 0) idxs[0] = idx_add;
   // Round 0 of the exchange: every part publishes the XCD it runs on (agent-scope words, valid wherever the parts sit).
-  // If all parts share one XCD — the placement the block numbering aims for — later rounds publish with plain
-  // (workgroup-scope) stores that STAY in that XCD's L2, where the partners' L1-bypassing loads find them at L2-hit
-  // latency; agent-scope stores are written through to the fabric and dropped from L2, so every poll would pay a
-  // memory-side round trip.  Parts on different XCDs keep the agent-scope stores.
+  // With DET6D_FPS_COOP_FAST=1, parts that share one XCD — the placement the block numbering aims for — AND pass the
+  // handshake below publish later rounds with workgroup-scope stores that STAY in that XCD's L2, where the partners'
+  // L1-bypassing loads find them at L2-hit latency; agent-scope stores (the default) are written through to the fabric, so
+  // every poll pays a memory-side round trip.
   bool same_xcd;
   {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;          // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -201,7 +207,21 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    same_xcd = !force_agent && __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;
+    same_xcd = allow_fast && __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;
+    if (allow_fast) {
+      // handshake: does a WORKGROUP-scope store of every part reach this part's agent-scope loads?  (word 6 of the parity-0
+      // slots; bounded wait: a part that does not see all tokens publishes with agent scope)
+      unsigned long long *tok = exch + (size_t)part * kSlotWords + 6;
+      if (h == 0) __hip_atomic_store(tok, co_pack(0x5A5A0000u | (unsigned)part, 0x7ffffffeu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long *their_tok = exch + (size_t)(reader0 ? lane : 0) * kSlotWords + 6;
+      bool seen_all = false;
+      for (int spins1 = 0; spins1 < 4096 && !seen_all; ++spins1) {
+        const unsigned long long w1 = __hip_atomic_load(their_tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen_all = __ballot(reader0 && (unsigned)(w1 >> 32) != 0x7ffffffeu) == 0ull;
+        if (!seen_all) __builtin_amdgcn_s_sleep(1);
+      }
+      same_xcd = same_xcd && seen_all;
+    }
   }
   float cg_val = __builtin_inff(), cg_x = 0.f, cg_y = 0.f, cg_z = 0.f;
   int cg_k = 0;
@@ -329,13 +349,13 @@ CoopLayout coop_layout(int b, int n) {
                                      (unsigned *)nullptr, (unsigned)items, 0, 20 + scene_bits(b), (hipStream_t)0);
   L.cub_bytes = cub;
   size_t off = 0;
+  L.err = off; off = align(off + 256);          // first: its offset must not depend on b (a workspace serves launches of fewer scenes)
   L.keys_in = off; off = align(off + items * 4);
   L.keys_out = off; off = align(off + items * 4);
   L.vals_in = off; off = align(off + items * 4);
   L.vals_out = off; off = align(off + items * 4);
   L.cub = off; off = align(off + cub);
   L.exch = off; off = align(off + (size_t)b * 2 * 4 * kSlotWords * 8);
-  L.err = off; off = align(off + 256);
   L.total = off;
   return L;
 }
@@ -374,14 +394,14 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   const long long groups = (long long)b * n / 16;
   hipLaunchKernelGGL(coop_group_order_kernel, dim3((unsigned)((groups + 511) / 512)), dim3(512), 0, stream, groups, n, log2s, vals_out);
   const int grid = 8 * parts * ((b + 7) / 8);
-  // DET6D_FPS_COOP_AGENT=1: agent-scope publishing stores also when the parts of a scene share an XCD (see same_xcd)
-  static const int force_agent = det6d_switch_set("DET6D_FPS_COOP_AGENT") ? 1 : 0;
+  // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
+  static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
   if (parts == 4)
     hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err, force_agent);
+                       vals_out, idx, exch, err, allow_fast);
   else
     hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err, force_agent);
+                       vals_out, idx, exch, err, allow_fast);
   return det6d_check_launch("det6d_fps (cooperative)");
 }
 

@@ -55,8 +55,9 @@ def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None, idx
             if ctl is not None and hasattr(ctl, 'status_words'):
                 ctl.status_words.append(word)
             elif not torch.cuda.is_current_stream_capturing():
+                if len(PENDING_FPS_STATUS) >= 64:          # nobody drained the list: look at the words before any is dropped
+                    check_fps_status()
                 PENDING_FPS_STATUS.append(word)
-                del PENDING_FPS_STATUS[:-64]
 
 
 #: error words (int32 device views) of eager cooperative sampler launches that nobody has checked yet
@@ -106,12 +107,15 @@ def fps_is_cooperative(n):
 
 def fps_workspace(b, n, device='cuda'):
     """scratch of one sampler launch over b scenes of n points (det6d_fps_fused_workspace_bytes: (b, n) floats, more for
-    the cooperative sampler of 32768 / 65536-point scenes).  A cooperative workspace is zero-filled: its error word is
-    sticky and cleared only here and by a status read (the other samplers cannot fail after their launch: no fill)"""
+    the cooperative sampler of 32768 / 65536-point scenes).  Only the cooperative sampler's sticky error word (the first
+    bytes of its workspace: the same place whatever the number of scenes a launch covers) is cleared here — once, when the
+    workspace is made; launches never clear it, a status read does."""
     nbytes = int(L.lib().det6d_fps_fused_workspace_bytes(b, n))
-    if nbytes > 4 * b * n:
-        return torch.zeros((nbytes,), dtype=torch.uint8, device=device)
-    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    word = fps_status_word(b, n, ws)
+    if word is not None:
+        word.zero_()
+    return ws
 
 
 def gather_centres(xyz, idx, rows_out=None, zero_from=0, out=None, idx_bias=0):

@@ -326,7 +326,8 @@ class GraphedDet6D(object):
         # sticky error words travel to pinned memory next to the counts and are looked at in finalize()
         self._status_words = list(inline.status_words) if inline is not None else []
         self._status_host = torch.zeros((max(1, len(self._status_words)),), dtype=torch.int32, pin_memory=True)
-        self._front_status = None     # (host int32 tensor, device words) of the Det6DGroup this pass belongs to
+        self._front_group = None      # the Det6DGroup this pass belongs to (its stage-1 samplers' status: see Det6DGroup)
+        self._front_gen = -1          # generation of the group launch this pass's last launch_rest() belonged to
 
     def _relaunched(self):
         lazy = self.batch_dict.get('point_coords_list', None)
@@ -379,15 +380,13 @@ class GraphedDet6D(object):
         bad = []
         if self._status_words and bool(self._status_host[:len(self._status_words)].any()):
             bad += [w for w, f in zip(self._status_words, self._status_host.tolist()) if f]
-        if self._front_status is not None and bool(self._front_status[0].any()):
-            bad += [w for w, f in zip(self._front_status[1], self._front_status[0].tolist()) if f]
         if bad:
-            for w in bad:
-                w.zero_()
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(self.stream):     # ordered against the next replay of this pass
+                for w in bad:
+                    w.zero_()
             self._status_host.zero_()
-            if self._front_status is not None:
-                self._front_status[0].zero_()
+        front_bad = self._front_group is not None and self._front_group.launch_failed(self._front_gen)
+        if bad or front_bad:
             raise fused.FpsTimeout("a cooperative farthest-point sampler of this pass gave up waiting for its partner "
                                    "workgroups (include/det6d_ops.h: det6d_fps_fused_status): the pass's detections are invalid")
 
@@ -466,7 +465,12 @@ class Det6DGroup(object):
         hoisted = {(s['layer'], s['j']) for s in self.plan}
         self._status_words = [w for w in (fused.fps_status_word(nb, s['hi'] - s['lo'], self.ws[(s['layer'], s['j'])])
                                           for s in self.plan) if w is not None]
-        self._status_host = torch.zeros((max(1, len(self._status_words)),), dtype=torch.int32, pin_memory=True)
+        # One row of pinned status words per launch in flight (ring): every pass of a launch looks at ITS launch's row, so
+        # the first finalize() that sees a failure does not hide it from the other k-1 passes of that launch.
+        self._status_ring = 16
+        self._status_host = torch.zeros((self._status_ring, max(1, len(self._status_words))), dtype=torch.int32, pin_memory=True)
+        self._gen = 0                 # launches so far
+        self._cleared_gen = -1        # last failed launch whose device words have been cleared
         self.runners = []
         for j in range(k):
             sl = slice(j * batch_size, (j + 1) * batch_size)
@@ -477,7 +481,7 @@ class Det6DGroup(object):
                                              stream=None if main_streams is None else main_streams[j % len(main_streams)]))
         if self._status_words:
             for r in self.runners:
-                r._front_status = (self._status_host, self._status_words)
+                r._front_group = self
         self._fused = fused
         self._sampled = torch.cuda.Event()
         self._count = k
@@ -498,14 +502,32 @@ class Det6DGroup(object):
                 if step['feeds']:     # xyz of these picks: the cloud the next layer's hoisted sampler works on
                     F.gather_centres(src, idx[:nb, step['offset']:step['offset'] + step['m']], out=self.ctr_all[key][:nb],
                                      idx_bias=-step['bias'])
-            for i, w in enumerate(self._status_words):     # sticky error words -> pinned memory, looked at in finalize()
-                self._status_host[i:i + 1].copy_(w, non_blocking=True)
+            self._gen += 1
+            row = self._status_host[self._gen % self._status_ring]
+            for i, w in enumerate(self._status_words):     # sticky error words -> this launch's pinned row, looked at in finalize()
+                row[i:i + 1].copy_(w, non_blocking=True)
             self._sampled.record(self.hi)
         return self
+
+    def launch_failed(self, gen):
+        """did a hoisted sampler give up in (or before, and unreported until) launch `gen`?  Every pass of that launch gets
+        the same answer.  The device words are sticky: they are cleared here, once per failed launch, on the sampler stream
+        (ordered against the next stage-1 launch), so launches issued before the clear report the failure too."""
+        if gen < 0 or gen <= self._gen - self._status_ring:
+            return False
+        if not bool(self._status_host[gen % self._status_ring].any()):
+            return False
+        if gen > self._cleared_gen:
+            self._cleared_gen = gen
+            with torch.cuda.stream(self.hi):
+                for w in self._status_words:
+                    w.zero_()
+        return True
 
     def launch_rest(self):
         active = self.runners[:self._count]
         for r in active:
+            r._front_gen = self._gen
             r.launch_rest(self._sampled)
         return active
 

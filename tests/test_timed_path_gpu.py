@@ -393,6 +393,29 @@ def test_sampler_failure_is_raised_by_finalize():
     torch.cuda.synchronize()
     assert int(group._status_words[0]) == 0
     group.launch()[0].finalize()                                   # cleared: the next pass is fine again
+    # a group of k = 2 passes: (1) the word sits at the same place for a PARTIAL launch (count < k: fewer scenes through the
+    # same workspace), (2) EVERY pass of the failed launch raises, not only the first one finalized
+    pts2 = torch.from_numpy(flat_points(make_batch(8401, b, n))).cuda()
+    g2 = Det6DGroup(model, b, n, 2, torch.cuda.Stream(), points=[pts, pts2], main_streams=[torch.cuda.Stream(), torch.cuda.Stream()])
+    assert fused.fps_status_word(1, n, g2.ws[(0, 0)]).data_ptr() == fused.fps_status_word(2, n, g2.ws[(0, 0)]).data_ptr()
+    for r_ in g2.launch():
+        r_.finalize()
+    g2._status_words[0].fill_(1)
+    torch.cuda.synchronize()
+    (only,) = g2.launch(count=1)                                   # partial group
+    with pytest.raises(fused.FpsTimeout):
+        only.finalize()
+    torch.cuda.synchronize()
+    assert int(g2._status_words[0]) == 0
+    g2._status_words[0].fill_(1)
+    torch.cuda.synchronize()
+    both = g2.launch()
+    for r_ in both:                                                # both passes of the failed launch report it
+        with pytest.raises(fused.FpsTimeout):
+            r_.finalize()
+    torch.cuda.synchronize()
+    for r_ in g2.launch():                                         # cleared once: the next launch is fine
+        r_.finalize()
     # single-graph pass: the word of the sampler captured inside the graph
     runner = GraphedDet6D(model, b, n)
     assert runner._status_words
