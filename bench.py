@@ -114,6 +114,9 @@ def child_rate(args, env_extra, extra_args=(), note="", roofline=False):
         if d.get("roofline"):            # the leg's own GEMM-family roofline (its own flop count: the balls' fill differs)
             res["algorithmic_gflop_per_pass"] = d["roofline"]["algorithmic_gflop_per_pass"]
             res["roofline"] = d["roofline"]
+        if d.get("index_kernels"):       # stand-alone sampler / query rates of the leg's shapes (us per dependent pick)
+            res["fps_us_per_round"] = d["index_kernels"]["fps_us_per_round"]
+            res["index_kernels"] = d["index_kernels"]
         if note:
             res["note"] = note
         return res
@@ -154,8 +157,17 @@ def orchestrate(args):
             ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
             ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
         ]
-        line["other_configs"] = {name: child_rate(args, {}, extra, roofline=not args.no_roofline and '--scene' in extra)
+        line["other_configs"] = {name: child_rate(args, {}, extra, roofline=not args.no_roofline and ('--scene' in extra or '65536' in extra))
                                  for name, extra in legs}
+        # both density regimes in the part of the line the driver parses: `value` is the benchmark generator's (sparse balls),
+        # the same engine on ray-cast scenes (KITTI-like density, 2.7x the information rows) is quoted beside it
+        ray = line["other_configs"].get(legs[3][0], {})
+        if "scenes_per_s" in ray:
+            line["config"]["raycast_scenes_per_s"] = ray["scenes_per_s"]
+            if isinstance(line.get("roofline"), dict) and ray.get("roofline"):
+                line["roofline"]["raycast"] = {"scenes_per_s": ray["scenes_per_s"], "frac": ray["roofline"]["frac"],
+                                               "achieved": ray["roofline"]["achieved"],
+                                               "algorithmic_gflop_per_pass": ray["roofline"]["algorithmic_gflop_per_pass"]}
         # the reference's timed loop includes load_data_to_gpu (core/tools/eval_utils/eval_utils.py:53-56): the same stream of
         # steps with every batch uploaded from pinned host memory on its pass's sampler stream.  Never `value`.
         line["h2d_inclusive"] = child_rate(args, {}, ['--h2d'],
@@ -481,6 +493,18 @@ def main():
             line["latency"] = {"ms_per_batch": round((time.perf_counter() - t0) / 5 * 1e3, 3),
                                "note": "one batch of %d scenes, one captured graph on one stream, idle chip" % b}
             del lat
+            # one frame, idle chip: the shape of the reference's single-frame callers (sim/gazebo/src/detection/script/
+            # detection.py:108-126,185-188; core/tools/demo.py)
+            one = torch.from_numpy(synth_points(4242, 1, n, tilt=args.tilt, scene=args.scene)).cuda()
+            lat1 = GraphedDet6D(model, 1, n, points=one)
+            lat1.launch(); lat1.finalize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                lat1.launch(); lat1.finalize()
+            line["latency_b1"] = {"ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 3),
+                                  "note": "ONE scene of %d points, one captured graph on one stream, idle chip, host launch -> "
+                                          "detections on the host" % n}
+            del lat1, one
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS)
             line["roofline"]["scenes_per_pass"] = b * merge
@@ -492,9 +516,12 @@ def main():
             torch.cuda.empty_cache()
             line["pipeline"] = pipeline_rate(cfg, model, b * merge, n, group=args.group, n_main=depth, prefetch=args.prefetch)
         elif world == 1 and args.leg_roofline:
-            line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS, pmc_tag=args.scene)
+            line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS,
+                                               pmc_tag='65536' if n == 65536 else args.scene)
             line["roofline"]["scenes_per_pass"] = b * merge
             line["compact_fill"] = compact_fill(model, points, b)
+            if n != 16384:               # the samplers / queries of this leg's shapes (the 65536-point cooperative sampler)
+                line["index_kernels"] = index_kernel_rates(model, points, b, n)
         elif world == 1:
             line["compact_fill"] = compact_fill(model, points, b)
         if world == 1 and args.cpu_scenes > 0:

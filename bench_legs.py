@@ -252,9 +252,12 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None, pmc_tag
     dense = flops_per_scene * batch
     achieved = useful / (total_ms * 1e-3) / 1e12
     traffic = None
-    # committed PMC summaries: profiles/rNN_<tag>_pmc_summary.json with tag "beam" for the ray-cast scenes
-    pmc = sorted(f for f in __import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json'))
-                 if ('beam' in os.path.basename(f)) == (pmc_tag == 'beam'))
+    # committed PMC summaries: profiles/rNN_<tag>_pmc_summary.json — tag "beam" for the ray-cast scenes, "65536" for the
+    # 65536-point scenes, anything else for the benchmark scenes; the latest round's file wins
+    def _kind(f):
+        f = os.path.basename(f)
+        return 'beam' if 'beam' in f else '65536' if '65536' in f else 'uniform'
+    pmc = sorted(f for f in __import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')) if _kind(f) == pmc_tag)
     if os.environ.get('DET6D_DENSE_ROWS'):
         pmc = []
     if pmc:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)

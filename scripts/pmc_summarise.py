@@ -44,4 +44,28 @@ if gemm and all('FETCH_SIZE' in g and 'WRITE_SIZE' in g for g in gemm):
         d['mfma_busy_cycles_per_step'] = busy
         d['sq_busy_cycles_per_step'] = sq
     res['_derived'] = {'linear_kernel': d}
+# per-family ratios (round 4): how busy the matrix pipe is, what the vector ALU issues beside it, what the LDS costs
+ratios = {}
+for fam, c in res.items():
+    if fam == '_derived':
+        continue
+    r = {}
+    if c.get('GRBM_GUI_ACTIVE') and c.get('SQ_VALU_MFMA_BUSY_CYCLES') is not None:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums 4 SIMDs x 256 CUs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks while the kernel runs
+        r['matrix_pipe_busy_frac'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (c['GRBM_GUI_ACTIVE'] / 8.0), 4)
+    if c.get('SQ_INSTS_MFMA'):
+        r['valu_insts_per_mfma'] = round((c.get('SQ_INSTS_VALU', 0.0) - c['SQ_INSTS_MFMA']) / c['SQ_INSTS_MFMA'], 3)
+        r['lds_insts_per_mfma'] = round(c.get('SQ_INSTS_LDS', 0.0) / c['SQ_INSTS_MFMA'], 3)
+    if c.get('SQ_LDS_IDX_ACTIVE'):
+        r['lds_bank_conflict_frac_of_lds_cycles'] = round(c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE'], 4)
+    if c.get('SQ_WAVE_CYCLES'):
+        for k, name in (('SQ_WAIT_INST_LDS', 'wait_inst_lds'), ('SQ_WAIT_INST_ANY', 'wait_inst_any'), ('SQ_WAIT_ANY', 'wait_any'),
+                        ('SQ_ACTIVE_INST_ANY', 'active_inst_any'), ('SQ_ACTIVE_INST_VALU', 'active_inst_valu'),
+                        ('SQ_ACTIVE_INST_LDS', 'active_inst_lds')):
+            if k in c:
+                r[name + '_frac_of_wave_cycles'] = round(c[k] / c['SQ_WAVE_CYCLES'], 4)
+    if r:
+        ratios[fam] = r
+if ratios:
+    res.setdefault('_derived', {})['per_family'] = ratios
 print(json.dumps(res, indent=1, sort_keys=True))
