@@ -24,6 +24,19 @@ static inline int det6d_check_launch(const char *what) {
 
 static inline int det6d_divup(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (call site, device) — a
+// process-wide "done" flag would leave a second device of the process at the default limit.  The race of two host threads on
+// the remembered device only repeats an idempotent call.
+#define DET6D_MAX_DYNAMIC_LDS(kernel, bytes)                                                                       \
+  do {                                                                                                              \
+    static int d6_attr_dev_ = -1;                                                                                   \
+    int d6_dev_ = 0;                                                                                                \
+    if (hipGetDevice(&d6_dev_) == hipSuccess && d6_attr_dev_ != d6_dev_) {                                          \
+      hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));        \
+      d6_attr_dev_ = d6_dev_;                                                                                       \
+    }                                                                                                               \
+  } while (0)
+
 // Environment switches.  Two kinds:
 //  * det6d_switch_*: select between implementations that give IDENTICAL results (the default kernel or an exact
 //    fallback the parity tests also cover: DET6D_FPS_SKIP, DET6D_FPS_CELLS_MIN_N, DET6D_LINEAR_NO_FAST,

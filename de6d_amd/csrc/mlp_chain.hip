@@ -776,12 +776,7 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
     const int wb = det6d_divup(ntiles, 8) < 256 ? det6d_divup(ntiles, 8) : 256;
 #define D6_WIDE(C2V, NSV)                                                                                              \
   do {                                                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<C2V, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                          (int)lds_bytes);                                                                             \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    DET6D_MAX_DYNAMIC_LDS((mlp_chain_wide_kernel<C2V, NSV>), lds_bytes);                                               \
     hipLaunchKernelGGL((mlp_chain_wide_kernel<C2V, NSV>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);     \
   } while (0)
     if (c2 == 64 && ns == 16) D6_WIDE(64, 16);
@@ -839,18 +834,10 @@ DET6D_API int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *
     const size_t lds_bytes = sizeof(float) * ((size_t)70 * 64 + (size_t)66 * c2 + (size_t)c2 * 128);
     const int wb = det6d_divup(ntiles, 8) < 256 ? det6d_divup(ntiles, 8) : 256;
     if (c2 == 64) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<64, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-      }
+      DET6D_MAX_DYNAMIC_LDS((mlp_chain_wide_kernel<64, 32, true>), lds_bytes);
       hipLaunchKernelGGL((mlp_chain_wide_kernel<64, 32, true>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);
     } else {
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<96, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-      }
+      DET6D_MAX_DYNAMIC_LDS((mlp_chain_wide_kernel<96, 32, true>), lds_bytes);
       hipLaunchKernelGGL((mlp_chain_wide_kernel<96, 32, true>), dim3(wb), dim3(512), lds_bytes, (hipStream_t)stream, g);
     }
     return det6d_check_launch("det6d_mlp_chain3_compact");

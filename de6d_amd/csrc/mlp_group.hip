@@ -588,11 +588,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
 template <int C1, int C2, int C3, bool COMPACT>
 int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
   const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64 + 4 * 64 * 4);   // + tags + store scratch
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void *)mlp_group_stream_kernel<C1, C2, C3, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
-  }
+  DET6D_MAX_DYNAMIC_LDS((mlp_group_stream_kernel<C1, C2, C3, COMPACT>), lds_bytes);
   int blocks = g.rows / 32;
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL((mlp_group_stream_kernel<C1, C2, C3, COMPACT>), dim3(blocks), dim3(256), lds_bytes, stream, g);

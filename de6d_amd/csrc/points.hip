@@ -359,21 +359,25 @@ DET6D_API int det6d_three_interpolate(int b, int c, int m, int n, const float *p
   if (b < 0 || c < 0 || n < 0 || m < 0 || !points || !idx || !weight || !out) return DET6D_EINVAL;
   const int64_t total = (int64_t)b * c * n;
   if (total == 0) return DET6D_OK;
-  // channel rows through LDS when 4 of them fit 64 KB (two workgroups per CU) and the grid fills the chip
-  constexpr int CH = 4;
-  if (m > 0 && (size_t)m * CH * 4 <= 64 * 1024 && n >= 1024 && b <= 65535 && det6d_divup(c, CH) <= 65535) {
-    int splits = det6d_divup(1024, b * det6d_divup(c, CH));          // >= ~1024 workgroups in all
+  // channel rows through LDS: as many (4, 2 or 1) as fit 64 KB (two workgroups per CU): m <= 4096 / 8192 / 16384.  Like the
+  // reference's kernel (interpolate_gpu.cu:84-104) it trusts idx to lie in [0, m).
+  const int ch = m <= 0 ? 0 : (size_t)m * 16 <= 64 * 1024 ? 4 : (size_t)m * 8 <= 64 * 1024 ? 2 : (size_t)m * 4 <= 64 * 1024 ? 1 : 0;
+  if (ch && n >= 1024 && b <= 65535 && det6d_divup(c, ch) <= 65535) {
+    int splits = det6d_divup(1024, b * det6d_divup(c, ch));          // >= ~1024 workgroups in all
     if (splits < 1) splits = 1;
     int pts = det6d_divup(det6d_divup(n, splits), 256) * 256;
     if (pts < 256) pts = 256;
-    const size_t lds = (size_t)m * CH * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void *)three_interpolate_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(three_interpolate_lds_kernel<CH>, dim3(det6d_divup(n, pts), det6d_divup(c, CH), b), dim3(256), lds, S(stream), c, m, n,
-                       pts, points, idx, weight, out);
+    const size_t lds = (size_t)m * ch * 4;
+    const dim3 grid(det6d_divup(n, pts), det6d_divup(c, ch), b);
+#define D6_INTERP_LDS(CH)                                                                                                     \
+  do {                                                                                                                        \
+    DET6D_MAX_DYNAMIC_LDS(three_interpolate_lds_kernel<CH>, 64 * 1024);                                                         \
+    hipLaunchKernelGGL(three_interpolate_lds_kernel<CH>, grid, dim3(256), lds, S(stream), c, m, n, pts, points, idx, weight, out); \
+  } while (0)
+    if (ch == 4) D6_INTERP_LDS(4);
+    else if (ch == 2) D6_INTERP_LDS(2);
+    else D6_INTERP_LDS(1);
+#undef D6_INTERP_LDS
     return det6d_check_launch("det6d_three_interpolate");
   }
   hipLaunchKernelGGL(three_interpolate_kernel, grid_for(total), dim3(kBlock), 0, S(stream), total, c, m,

@@ -33,12 +33,15 @@ def _packed_calibs(batch_dict, count, dev):
     key = (tuple(id(batch_dict['calib'][i]) for i in range(count)), tuple(shapes), str(dev))
     hit = _CALIB_CACHE.get(key)
     if hit is not None and all(a is b for a, b in zip(hit[1], batch_dict['calib'][:count])):
+        torch.cuda.current_stream(dev).wait_event(hit[2])        # uploaded on another stream, perhaps a moment ago
         return hit[0]
     calib = np.stack([batch_dict['calib'][i].packed(shapes[i]) for i in range(count)])
     t = torch.from_numpy(calib).to(dev)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
     if len(_CALIB_CACHE) > 64:
         _CALIB_CACHE.clear()
-    _CALIB_CACHE[key] = (t, list(batch_dict['calib'][:count]))     # the objects are kept alive: ids stay unique
+    _CALIB_CACHE[key] = (t, list(batch_dict['calib'][:count]), ready)     # the objects are kept alive: ids stay unique
     return t
 
 
@@ -81,14 +84,23 @@ def convert_batch(batch_dict, pred_dicts):
     dev = pred_dicts[0]['pred_boxes'].device
     calib = _packed_calibs(batch_dict, len(pred_dicts), dev)
     block = _padded_block(pred_dicts) if pred_dicts[0]['pred_boxes'].dtype == torch.float32 else None
+    if block is not None and block[0].shape[1] > 4 * max(counts):
+        block = None        # mostly empty slots: converting and copying P slots per frame would cost more than the three gathers
     if block is not None:
-        # every slot of the padded block is converted (slots past a frame's count hold stale boxes: computed, never read)
+        # every slot of the padded block is converted (slots past a frame's count hold zeros or earlier detections — the block
+        # is cleared when it is made, runtime.GraphedDet6D — computed, never read)
         bx, sc, lb = block
         f, pmax, ncol = bx.shape
         key = (f, pmax, str(dev))
-        scene_of = _SCENE_OF_CACHE.get(key)
-        if scene_of is None:
-            scene_of = _SCENE_OF_CACHE[key] = torch.arange(f, dtype=torch.int32, device=dev).repeat_interleave(pmax).contiguous()
+        hit = _SCENE_OF_CACHE.get(key)
+        if hit is None:
+            scene_of = torch.arange(f, dtype=torch.int32, device=dev).repeat_interleave(pmax).contiguous()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            _SCENE_OF_CACHE[key] = (scene_of, ready)
+        else:
+            scene_of = hit[0]
+            torch.cuda.current_stream(dev).wait_event(hit[1])
         boxes = bx.reshape(f * pmax, ncol)
         annos = fused.kitti_annos(boxes, scene_of, calib)
         packed = torch.cat([annos, boxes, sc.reshape(-1, 1).float(), lb.reshape(-1, 1).float()], 1).cpu().numpy().reshape(f, pmax, -1)

@@ -319,6 +319,13 @@ class GraphedDet6D(object):
                     self.batch_dict, (self.boxes, self.scores, self.labels, self.index, self.count) = body()
             finally:
                 fused.SAMPLER_SEGMENTS = None
+        # The result block (B, P, .) is static across replays and its slots past a scene's count are never written: clear it
+        # once, so that a consumer that converts whole blocks (datasets/kitti: convert_batch) reads zeros or earlier finite
+        # detections there, never uninitialised memory
+        with torch.cuda.stream(self.stream):
+            for t in (self.boxes, self.scores, self.labels):
+                t.zero_()
+        self.stream.synchronize()
         self.count_host = torch.empty(self.count.shape, dtype=self.count.dtype, pin_memory=True)
         self.done = torch.cuda.Event()
         self._weights_version = getattr(model, 'weights_version', 0)

@@ -143,7 +143,7 @@ def test_padded_result_block_fast_path_equals_the_generic_path():
     counts = [100, 0, 37, 1, 64, 5]
     views = [{'pred_boxes': boxes[i, :k], 'pred_scores': scores[i, :k], 'pred_labels': labels[i, :k]} for i, k in enumerate(counts)]
     copies = [{k_: v.clone() for k_, v in p.items()} for p in views]
-    for lo, hi in ((0, 6), (2, 5), (1, 2)):
+    for lo, hi in ((0, 6), (2, 5), (1, 2), (3, 4), (5, 6)):     # the last two: P > 4 x the largest count -> the generic path serves views too
         batch = {'frame_id': ['%06d' % i for i in range(lo, hi)], 'calib': calibs[lo:hi],
                  'image_shape': np.tile(np.array([[375, 1242]], np.int32), (hi - lo, 1))}
         assert kd._padded_block(views[lo:hi]) is not None
