@@ -124,6 +124,14 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["det6d_version", "det6d_last_erro
 _lib = None
 
 
+def experiment_switch(name, default=None):
+    """value of an alternative-route variable (DET6D_NO_EXPAND, DET6D_COMPACT_SPLIT, ...) — honoured only together with
+    DET6D_EXPERIMENTS_LIB=1, i.e. in the experiments build; the shipped configuration has ONE route per shape"""
+    if not os.environ.get("DET6D_EXPERIMENTS_LIB"):
+        return default
+    return os.environ.get(name, default)
+
+
 def lib():
     """Load libdet6d_hip.so (after torch, so both share torch's libamdhip64.so.7)."""
     global _lib

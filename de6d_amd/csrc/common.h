@@ -38,12 +38,12 @@ static inline int det6d_divup(int a, int b) { return (a + b - 1) / b; }
   } while (0)
 
 // Environment switches.  Two kinds:
-//  * det6d_switch_*: select between implementations that give IDENTICAL results (the default kernel or an exact
-//    fallback the parity tests also cover: DET6D_FPS_SKIP, DET6D_FPS_CELLS_MIN_N, DET6D_LINEAR_NO_FAST,
-//    DET6D_CHAIN_LDS, DET6D_CHAIN_NO_WIDE).  Always compiled.
-//  * det6d_env_*: tile sweeps, timing hooks and stand-ins used by scripts/experiments.  Compiled to their default
-//    unless the library is built with -DDET6D_EXPERIMENTS (python -m de6d_amd._build --experiments): the shipped
-//    library ignores those variables.
+//  * det6d_switch_*: read by the SHIPPED library: DET6D_FPS_COOP_FAST (fps_coop.hip) and nothing else (DET6D_DENSE_ROWS is
+//    read by the Python side).
+//  * det6d_env_*: alternative kernel routes (all result-preserving: DET6D_LINEAR_NO_FAST, DET6D_CHAIN_LDS,
+//    DET6D_CHAIN_NO_WIDE, DET6D_ROWS_RB, DET6D_GROUP_STREAM, DET6D_GROUP_PRE), tile sweeps, timing hooks and stand-ins used by
+//    scripts/experiments and by the route tests.  Compiled to their default unless the library is built with
+//    -DDET6D_EXPERIMENTS (python -m de6d_amd._build --experiments): the shipped library ignores those variables.
 static inline int det6d_switch_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;

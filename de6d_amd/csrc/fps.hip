@@ -482,10 +482,9 @@ DET6D_API int det6d_fps_weights(int b, int n, int m, const float *xyz, const flo
   return launch_fps<true>(b, n, m, xyz, weights, temp, idx, dense_view(n, m), (hipStream_t)stream);
 }
 
-// fps_cells.hip: exact spatially pruned D-FPS (Morton cells + bounding-box skip test)
-int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
-                           long long idx_bstride, int idx_add, int init_temp, const float *xyz,
-                           const float *temp, int *perm, int *idx, hipStream_t stream);
+// fps_cells.hip: exact spatially pruned D-FPS of 16384-point scenes (k-d regions + bounding-box skip test)
+int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                           const float *xyz, int *perm, int *idx, hipStream_t stream);
 
 #ifdef DET6D_EXPERIMENTS
 // ---- profiling stand-ins (DET6D_FPS_STANDIN=1|2, never a result path; scripts/experiments/gpu_whatif.py): only in
@@ -578,31 +577,21 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
     return det6d_check_launch("det6d_fps_fused(stand-in)");
   }
 #endif
-  // Opt-in (DET6D_FPS_CELLS_MIN_N=4096|8192|16384): the exact spatially pruned cell sampler of
-  // fps_cells.hip (its Morton permutation lives in `temp`, which is free because the min-distances start
-  // at 1e10 implicitly).  Bit-exact, but measured on MI355X at 1.39 us/round for 16384 points against
-  // 1.35 for the fat-thread kernel: only ~5 of 256 cells are touched per round, yet the per-round
-  // latency chain (box test, per-cell DPP arg-max, two reductions, LDS hand-off, barrier; 0.62 us with
-  // zero cells touched) costs what the pruning saves.  Kept off by default until that chain is shorter.
-  static const int cells_min_n = det6d_switch_int("DET6D_FPS_CELLS_MIN_N", (1 << 30));
-  // Default for 16384 points: the wave-skip sampler of fps_cells.hip (Morton-sorted fat threads, one bounding
-  // box per wave; 16 waves x 16 points per lane by default, DET6D_FPS_SKIP=8: 8 x 32, =0: the plain fat-thread
-  // kernel).  Same picks bit for bit, 0.96 (1.16) vs 1.35 us per round and a fraction of the vector-ALU work.
-  static const int skip_mode = det6d_switch_int("DET6D_FPS_SKIP", 16);
   // 32768 / 65536 points: the scene is held in registers by 2 / 4 cooperating workgroups (fps_coop.hip) when the caller
-  // supplied the workspace det6d_fps_fused_workspace_bytes asks for; otherwise (or DET6D_FPS_COOP=0) the
-  // memory-resident kernel below, 100x slower, same picks
-  static const int coop_on = det6d_switch_int("DET6D_FPS_COOP", 1);
-  if (coop_on && temp && x && out && b > 0 && m > 0 && det6d_fps_coop_handles(n)) {
+  // supplied the workspace det6d_fps_fused_workspace_bytes asks for; otherwise the memory-resident kernel below, 100x
+  // slower, same picks
+  if (temp && x && out && b > 0 && m > 0 && det6d_fps_coop_handles(n)) {
     char *ws = reinterpret_cast<char *>(((uintptr_t)temp + 255) & ~(uintptr_t)255);
     const long long avail = temp_bytes - (ws - reinterpret_cast<char *>(temp));
     const long long need = det6d_fps_coop_workspace_bytes(b, n);
     if (need > 0 && avail >= need)
       return det6d_fps_coop_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x, ws, out, (hipStream_t)stream);
   }
-  const bool use_cells = n >= cells_min_n && (n == 16384 || n == 8192 || n == 4096);
-  if (temp && x && out && b > 0 && m > 0 && (use_cells || (skip_mode && n == 16384)))
-    return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, 0, vw.idx_bstride, lo + idx_bias, 1, x, nullptr,
+  // 16384 points: the wave-skip sampler of fps_cells.hip (k-d sorted fat threads, one bounding box per wave; its
+  // permutation lives in `temp`, which is free because the min-distances start at 1e10 implicitly): same picks bit for bit,
+  // 0.83 vs 1.35 us per pick and a fraction of the vector-ALU work of the plain fat-thread kernel
+  if (temp && x && out && b > 0 && m > 0 && n == 16384)
+    return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x,
                                   reinterpret_cast<int *>(temp), out, (hipStream_t)stream);
   return launch_fps<false>(b, n, m, x, nullptr, temp, out, vw, (hipStream_t)stream);
 }

@@ -1,26 +1,17 @@
-// fps_cells.hip — exact, spatially pruned farthest point sampling (D-FPS) for gfx950.
+// fps_cells.hip — exact, spatially pruned farthest point sampling (D-FPS) of 16384-point scenes for gfx950.
 //
 // Same result, bit for bit, as farthest_point_sampling_kernel
-// (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222) including its tie order,
-// but a round no longer touches every point.
+// (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222) including its tie order, but a pick no longer
+// touches every point.
 //
-// Observation.  All min-distances satisfy temp[k] <= M, where M is the value of the previous pick
-// (the current maximum).  A point can only change in this round if d(k, s) < temp[k] <= M.  Points are
-// pre-sorted along a Morton curve and cut into cells of 64 (one wave64 register slot each); a cell
-// whose bounding box is at least sqrt(M) away from the new sample s cannot change, and its cached
-// arg-max stays valid.  The box test is exact in floating point: subtraction, multiplication and fma
-// are monotone, so  lb = fma(gz,gz, fma(gx,gx, gy*gy))  with per-axis gaps g <= |x_k - s| is a true
-// lower bound of the distance the kernel would compute for every point of the cell.
-// After a few hundred picks only ~5 of the 256 cells of a 16384-point scene are touched per round.
-//
-// Structure per round (one workgroup per scene, NW waves, CPW cells per wave, cell g lives in wave
-// g % NW so that neighbouring cells are updated by different waves in parallel):
-//   1. lanes 0..CPW-1 test "their" cell's box against (s, M)          -> ballot = cells to update
-//   2. for each such cell: 7 VALU ops on its 64 points, one DPP max, cache (max, index, xyz) in lane c
-//   3. wave arg-max over the cached cell maxima (lanes 0..CPW-1), one LDS slot per wave, one barrier,
-//      block arg-max over NW slots -> new s, M.
-// Ties (exactly equal maxima: duplicated points) are rare and resolved on a slow path with the
-// reference's order: minimise (bitrev(k mod S), k).
+// Observation.  All min-distances satisfy temp[k] <= M, where M is the current maximum of a region.  A point can only change
+// in this round if d(k, s) < temp[k] <= M.  Points are pre-sorted into a 4 x 4 k-d grid of equal counts (cell_sort_kernel),
+// one cell per wave; a wave whose bounding box is at least sqrt(M) away from the new sample s cannot change, and its cached
+// arg-max stays valid.  The box test is exact in floating point: subtraction, multiplication and fma are monotone, so
+// lb = fma(gz,gz, fma(gx,gx, gy*gy))  with per-axis gaps g <= |x_k - s| is a true lower bound of the distance the kernel
+// would compute for every point of the cell.  A new sample reaches 1.3 of the 16 boxes on average.
+// Ties (exactly equal maxima: duplicated points) are resolved on a slow path with the reference's order:
+// minimise (bitrev(k mod S), k).
 #include "common.h"
 #include <stdlib.h>
 
@@ -55,15 +46,6 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
 // Pre-pass: spatial order of a scene.  perm[b, p] = original index of the point at sorted position p.
 // Any permutation is CORRECT for the samplers below; the order only makes their regions compact.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned part1by1(unsigned v) {
-  v &= 0xFFFFu;
-  v = (v | (v << 8)) & 0x00FF00FFu;
-  v = (v | (v << 4)) & 0x0F0F0F0Fu;
-  v = (v | (v << 2)) & 0x33333333u;
-  v = (v | (v << 1)) & 0x55555555u;
-  return v;
-}
-
 template <int IPT>
 __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bstride, const float *__restrict__ xyz,
                                                          int *__restrict__ perm) {
@@ -120,137 +102,6 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bs
   Sort(sort_tmp).Sort(key, val, 0, 22);
 #pragma unroll
   for (int i = 0; i < IPT; ++i) perm[tid * IPT + i] = val[i];
-}
-
-// ------------------------------------------------------------------------------------------------
-// The sampler
-// ------------------------------------------------------------------------------------------------
-struct CellSlot {
-  float val;
-  int idx;
-  float x, y, z;
-  float pad[3];
-};
-
-template <int NW, int CPW>
-struct CellState {
-  float px[CPW], py[CPW], pz[CPW], pt[CPW];
-  int pk[CPW];
-  // cached per cell, valid in lane c (c < CPW)
-  float cmax, cbx, cby, cbz;
-  int cidx;
-};
-
-// update cell `c` (wave-uniform): scalar binary search down to the statically indexed slot
-template <int LO, int HI, int NW, int CPW>
-__device__ __forceinline__ void update_cell(int c, CellState<NW, CPW> &st, float cx, float cy, float cz,
-                                            int log2s) {
-  if constexpr (HI - LO == 1) {
-    constexpr int S = LO;
-    const int lane = threadIdx.x & 63;
-    const float d = d6_sqdist(st.px[S] - cx, st.py[S] - cy, st.pz[S] - cz);
-    const float t = d6_vmin(d, st.pt[S]);
-    st.pt[S] = t;
-    const float v = d6_wave_max(t);
-    const unsigned long long tie = __ballot(t == v);
-    int wl = __builtin_ctzll(tie);
-    if (__popcll(tie) != 1) wl = min_key_lane(tie, st.pk[S], log2s);
-    const float bx = d6_readlane_f(st.px[S], wl), by = d6_readlane_f(st.py[S], wl), bz = d6_readlane_f(st.pz[S], wl);
-    const int bi = d6_readlane_i(st.pk[S], wl);
-    if (lane == c) { st.cmax = v; st.cidx = bi; st.cbx = bx; st.cby = by; st.cbz = bz; }
-  } else {
-    constexpr int MID = (LO + HI) / 2;
-    if (c < MID) update_cell<LO, MID, NW, CPW>(c, st, cx, cy, cz, log2s);
-    else update_cell<MID, HI, NW, CPW>(c, st, cx, cy, cz, log2s);
-  }
-}
-
-template <int NW, int CPW>
-__global__ __launch_bounds__(64 * NW) void fps_cells_kernel(int n, int m, int log2s, long long xyz_bstride,
-                                                            long long temp_bstride, long long idx_bstride,
-                                                            int idx_add, int init_temp, int dbg,
-                                                            const float *__restrict__ xyz,
-                                                            const int *__restrict__ perm,
-                                                            const float *__restrict__ temp,
-                                                            int *__restrict__ idxs) {
-  static_assert(NW <= 16 && CPW <= 32, "layout");
-  __shared__ CellSlot slots[2][NW];
-  const int h = threadIdx.x, lane = h & 63, wave = h >> 6;
-  xyz += (size_t)blockIdx.x * xyz_bstride;
-  perm += (size_t)blockIdx.x * n;
-  if (temp) temp += (size_t)blockIdx.x * temp_bstride;
-  idxs += (size_t)blockIdx.x * idx_bstride;
-
-  CellState<NW, CPW> st;
-  float blo_x = 0.f, blo_y = 0.f, blo_z = 0.f, bhi_x = 0.f, bhi_y = 0.f, bhi_z = 0.f;
-  st.cmax = -1.f; st.cidx = 0; st.cbx = st.cby = st.cbz = 0.f;
-#pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    const int g = c * NW + wave;              // Morton cell index
-    const int k = perm[g * 64 + lane];
-    st.pk[c] = k;
-    st.px[c] = xyz[(size_t)k * 3 + 0];
-    st.py[c] = xyz[(size_t)k * 3 + 1];
-    st.pz[c] = xyz[(size_t)k * 3 + 2];
-    asm volatile("" : "+v"(st.px[c]), "+v"(st.py[c]), "+v"(st.pz[c]));
-    st.pt[c] = init_temp ? 1e10f : temp[k];
-    const float lx = d6_wave_min(st.px[c]), hx = d6_wave_max(st.px[c]);
-    const float ly = d6_wave_min(st.py[c]), hy = d6_wave_max(st.py[c]);
-    const float lz = d6_wave_min(st.pz[c]), hz = d6_wave_max(st.pz[c]);
-    if (lane == c) { blo_x = lx; bhi_x = hx; blo_y = ly; bhi_y = hy; blo_z = lz; bhi_z = hz; }
-  }
-
-  float cx = xyz[0], cy = xyz[1], cz = xyz[2];
-  float M = __builtin_inff();
-  if (h == 0) idxs[0] = idx_add;
-
-  for (int r = 1; r < m; ++r) {
-    // 1. which of my cells can change?
-    unsigned cells;
-    {
-      const float gx = fmaxf(0.f, fmaxf(blo_x - cx, cx - bhi_x));
-      const float gy = fmaxf(0.f, fmaxf(blo_y - cy, cy - bhi_y));
-      const float gz = fmaxf(0.f, fmaxf(blo_z - cz, cz - bhi_z));
-      const float lb = d6_sqdist(gx, gy, gz);
-      const bool act = lane < CPW && (r == 1 || (!(lb >= M) && !D6_DBG_IS(1)));
-      cells = (unsigned)__ballot(act);
-    }
-    // 2. update them
-    while (cells) {
-      const int c = __builtin_ctz(cells);
-      cells &= cells - 1;
-      update_cell<0, CPW, NW, CPW>(c, st, cx, cy, cz, log2s);
-    }
-    // 3. wave arg-max over the cached cell maxima
-    const float cv = lane < CPW ? st.cmax : -__builtin_inff();
-    const float wv = d6_wave_max(cv);
-    const unsigned long long tie = __ballot(cv == wv);
-    int cl = __builtin_ctzll(tie);
-    if (__popcll(tie) != 1) cl = min_key_lane(tie, st.cidx, log2s);
-    CellSlot *sl = slots[r & 1];
-    if (lane == cl) {
-      sl[wave].val = wv;
-      sl[wave].idx = st.cidx;
-      sl[wave].x = st.cbx; sl[wave].y = st.cby; sl[wave].z = st.cbz;
-    }
-    if (!D6_DBG_IS(2)) __syncthreads();
-    const int src = lane & (NW - 1);
-    const float v2 = lane < NW ? sl[src].val : -__builtin_inff();
-    const int i2 = sl[src].idx;
-    const float x2 = sl[src].x, y2 = sl[src].y, z2 = sl[src].z;
-    const float bmax = d6_wave_max(v2);
-    const unsigned long long tie2 = __ballot(v2 == bmax);
-    int ww = __builtin_ctzll(tie2);
-    if (__popcll(tie2) != 1) ww = min_key_lane(tie2, i2, log2s);
-    // the reference picks index 0 when nothing exceeds its -1 sentinel (never happens with finite data)
-    const bool found = bmax > -1.0f;
-    const int old = found ? d6_readlane_i(i2, ww) : 0;
-    cx = found ? d6_readlane_f(x2, ww) : xyz[0];
-    cy = found ? d6_readlane_f(y2, ww) : xyz[1];
-    cz = found ? d6_readlane_f(z2, ww) : xyz[2];
-    M = bmax;
-    if (h == 0) idxs[r] = old + idx_add;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,74 +301,23 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsign
 int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, long long xyz_bstride, long long idx_bstride,
                          int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream);
 
-// Called by fps.hip's launcher for D-FPS on the sizes below.  `perm` is (B, n) int32 scratch.
-int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long temp_bstride,
-                           long long idx_bstride, int idx_add, int init_temp, const float *xyz,
-                           const float *temp, int *perm, int *idx, hipStream_t stream) {
+// Called by fps.hip's launcher for D-FPS of 16384-point scenes with fresh min-distances.  `perm` is (B, n) int32 scratch.
+int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                           const float *xyz, int *perm, int *idx, hipStream_t stream) {
+  if (n != 16384) return DET6D_EINVAL;
   dim3 grid(b);
   static const int dbg = det6d_env_int("DET6D_FPS_DBG", 0);  // timing experiments only
-  // wave-skip sampler (default for fresh min-distances); DET6D_FPS_SKIP=0 falls through to the cell kernel,
-  // DET6D_FPS_SKIP=16 uses 16 waves x 16 slots instead of 8 x 32
-  static const int skip = det6d_switch_int("DET6D_FPS_SKIP", 16);
+  hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+  hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
 #ifdef DET6D_EXPERIMENTS
   // experiments build only, DET6D_FPS_SEQ=1: the multi-pick sampler (fps_seq.hip: several picks per barrier round from
   // published top-4 lists; exact; 0.73-0.78 us per pick stand-alone against 0.83-0.85, no gain in the pipeline, 2.7x slower
   // on clouds made of duplicated points: LABNOTES.md, round 4)
   static const int seq = det6d_env_int("DET6D_FPS_SEQ", 0);
-  if (seq && n == 16384 && init_temp) {
-    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
-    return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
-  }
+  if (seq) return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
 #endif
-  if (skip && n == 16384 && init_temp) {
-    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    // DET6D_FPS_SKIP: 16 = 16 waves x 16 slots, one box per wave (default: 0.97 us/round); 162 = the same with two
-    // boxes (8-slot groups) per wave (1.08: the second box test and reduction cost more than the shorter scans
-    // save); 8 = 8 waves x 32 slots (1.15); 84 = 8 x 32 in four 8-slot groups (1.36)
-#ifdef DET6D_EXPERIMENTS
-    static const int thin = det6d_env_int("DET6D_FPS_THIN", 0);   // timing only, WRONG picks: 4 workgroups of 4 waves per scene
-    if (thin) {
-      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<4, 16, 1, 2>), dim3(4 * b), dim3(256), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, dbg, xyz, perm, idx);
-      return det6d_check_launch("det6d_fps (thin what-if)");
-    }
-#endif
-    if (skip == 8) {
-      hipLaunchKernelGGL(skip_group_order_kernel<32>, dim3(1, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<8, 32, 1>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, dbg, xyz, perm, idx);
-    } else if (skip == 84) {
-      hipLaunchKernelGGL(skip_group_order_kernel<8>, dim3(4, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<8, 32, 4>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, dbg, xyz, perm, idx);
-    } else if (skip != 162) {
-      hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
-      static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
-      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, dbg, xyz, perm, idx);
-    } else {
-      hipLaunchKernelGGL(skip_group_order_kernel<8>, dim3(4, b), dim3(512), 0, stream, n, log2s, perm);
-      hipLaunchKernelGGL((fps_skip_kernel<16, 16, 2>), grid, dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, dbg, xyz, perm, idx);
-    }
-    return det6d_check_launch("det6d_fps (wave skip)");
-  }
-  if (n == 16384) {
-    hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    hipLaunchKernelGGL((fps_cells_kernel<8, 32>), grid, dim3(512), 0, stream, n, m, log2s, xyz_bstride,
-                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
-  } else if (n == 8192) {
-    hipLaunchKernelGGL((cell_sort_kernel<8>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    hipLaunchKernelGGL((fps_cells_kernel<4, 32>), grid, dim3(256), 0, stream, n, m, log2s, xyz_bstride,
-                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
-  } else if (n == 4096) {
-    hipLaunchKernelGGL((cell_sort_kernel<4>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    hipLaunchKernelGGL((fps_cells_kernel<4, 16>), grid, dim3(256), 0, stream, n, m, log2s, xyz_bstride,
-                       temp_bstride, idx_bstride, idx_add, init_temp, dbg, xyz, perm, temp, idx);
-  } else {
-    return DET6D_EINVAL;
-  }
-  return det6d_check_launch("det6d_fps (cells)");
+  static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
+  hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                     idx_add, dbg, xyz, perm, idx);
+  return det6d_check_launch("det6d_fps (wave skip)");
 }

@@ -628,7 +628,7 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
                         : a->mode == DET6D_A_COMPACT ? (size_t)a->n : (size_t)a->rows;
   const bool fits32 = a_rows * a->lda * 4 < 0xfff00000ull && (size_t)a->k * a->ldw * 4 < 0xfff00000ull &&
                       (size_t)a->rows * a->ldy * 4 < 0xfff00000ull;
-  static const bool no_fast = det6d_switch_set("DET6D_LINEAR_NO_FAST");
+  static const bool no_fast = det6d_env_set("DET6D_LINEAR_NO_FAST");
   if (!fits32 || no_fast) {   // same tiles, plain predicated loader
     if (a->ncols > 64) {
       if (gm * det6d_divup(a->ncols, 128) < 256)

@@ -755,7 +755,7 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   const bool wide = lda == 68 && c1 == 64 && (c2 == 64 || c2 == 96) && c3 == 128 && (ns == 32 || !(m & 1)) && !(ldw1 & 3) &&
                     !(ldw2 & 3) && !(ldw3 & 3) &&
                     !(((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)s1 | (uintptr_t)s2) & 15) &&
-                    !det6d_switch_set("DET6D_CHAIN_NO_WIDE");
+                    !det6d_env_set("DET6D_CHAIN_NO_WIDE");
   if (!wide) {
     if (lda < 4 || lda > kMaxK1 || (lda & 3) || ((uintptr_t)a & 15) || ldctr < 3) return DET6D_EINVAL;
     if (c1 <= 0 || c1 > kMaxC || c2 <= 0 || c2 > kMaxC || c3 <= 0 || c3 > kMaxC3) return DET6D_EINVAL;
@@ -788,7 +788,7 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
   }
   int blocks = det6d_divup(ntiles, kChainWaves);
   if (blocks > 256 * 6) blocks = 256 * 6;     // persistent-ish: amortise the weight staging over many tiles
-  static const bool use_lds_env = det6d_switch_set("DET6D_CHAIN_LDS");
+  static const bool use_lds_env = det6d_env_set("DET6D_CHAIN_LDS");
   const bool use_lds = use_lds_env || (ns == 16 && (m & 1));   // the register kernel pairs two centres of ONE batch per tile
   // register kernel: a grid of exactly one residency round (256 CUs x 4 SIMDs x 4 waves) so that every wave
   // walks the same number of tiles (1536 blocks left half the chip idle in the second round)

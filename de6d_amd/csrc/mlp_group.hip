@@ -666,7 +666,7 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   g.idx = idx; g.n = n; g.m = m; g.ns = ns; g.cnt = cnt;
   g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
   g.y = y; g.ldy = ldy; g.col0 = col0;
-  static const int pre_entries = det6d_switch_int("DET6D_GROUP_PRE", 1);
+  static const int pre_entries = det6d_env_int("DET6D_GROUP_PRE", 1);
   g.pre = pre_entries;
   g.yvec = (!(ldy & 3) && !(col0 & 3) && !((uintptr_t)y & 15)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
@@ -679,7 +679,7 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   // ahead of the producing phase (12.98 vs 12.87 k scenes/s, ray-cast scenes 6.06 vs 6.09 k).  Narrow group (default):
   // its one-pass form holds 143 registers with eight waves, i.e. one workgroup per CU; the streaming form runs it 8-10 %
   // faster with the chip full (196 -> 180 us, ray-cast scenes 446 -> 400 us) and the pipeline gains 0.5-0.7 %.
-  static const int stream_form = det6d_switch_int("DET6D_GROUP_STREAM", 2);
+  static const int stream_form = det6d_env_int("DET6D_GROUP_STREAM", 2);
   if ((stream_form & 1) && c1 == 256 && c2 == 512 && c3 == 1024)
     return compact ? launch_group_stream<256, 512, 1024, true>(g, s) : launch_group_stream<256, 512, 1024, false>(g, s);
   if ((stream_form & 2) && c1 == 256 && c2 == 256 && c3 == 512)

@@ -270,7 +270,7 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   for (int c = 0, o = 0; c < nchains; o += nlayers[c], ++c)
     for (int l = 0; l < nlayers[c]; ++l) max_tiles = max_tiles > (layers[o + l].n + 31) / 32 ? max_tiles : (layers[o + l].n + 31) / 32;
   // DET6D_ROWS_RB: 2 (default) = 64-row tiles for narrow stacks over >= 16384 rows, 3 = over any number of rows, 1 = never
-  static const int rb_env = det6d_switch_int("DET6D_ROWS_RB", 2);
+  static const int rb_env = det6d_env_int("DET6D_ROWS_RB", 2);
   const int rb = (rb_env >= 2 && g.kchunk == g.k0 && max_tiles <= 2 && (rows >= 16384 || rb_env == 3)) ? 2 : 1;
   const size_t lds_bytes = sizeof(float) * 32 * rb * ((size_t)(g.wa + 1) + (size_t)(g.wb + 1));
   if (lds_bytes > 160 * 1024) return DET6D_EINVAL;

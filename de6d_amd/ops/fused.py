@@ -161,11 +161,11 @@ class CompactRows:
 
 
 #: smallest row class of the compact lists (1, 2 or 4)
-COMPACT_SMIN = int(os.environ.get('DET6D_COMPACT_SMIN', '1'))
+COMPACT_SMIN = int(L.experiment_switch('DET6D_COMPACT_SMIN', '1'))
 COMPACT_SMALL_CLASSES = True
 #: centres with more than g hits take ceil(cnt / g) * g rows cut into power-of-two parts (20 = 16 + 4) whose maxima are
 #: combined by an atomic max, instead of being padded to the next power of two; the pooled buffer must be zeroed first
-COMPACT_SPLIT = int(os.environ.get('DET6D_COMPACT_SPLIT', '1'))   # the granule g (0: padding to the next power of two)
+COMPACT_SPLIT = int(L.experiment_switch('DET6D_COMPACT_SPLIT', '1'))   # the granule g (0: padding to the next power of two)
 
 
 def compact_groups(cnt, idx, n, zero=None):
@@ -276,7 +276,7 @@ def group_expand(p, pcol0, w, shift, act, c1, rows_pts, ctr, out, idx=None, comp
 
 
 #: wide grouped MLPs as one launch (csrc/mlp_group.hip); DET6D_NO_GROUP_KERNEL=1: expand + two GEMM launches
-GROUP_KERNEL = os.environ.get('DET6D_NO_GROUP_KERNEL') is None
+GROUP_KERNEL = L.experiment_switch('DET6D_NO_GROUP_KERNEL') is None
 
 
 def group_kernel_eligible(layers, ns, compact):
@@ -316,7 +316,7 @@ def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, c
 
 
 #: short stacks of plain layers in one launch (csrc/mlp_rows.hip); DET6D_NO_ROWS_KERNEL=1: one det6d_linear per layer
-ROWS_KERNEL = os.environ.get('DET6D_NO_ROWS_KERNEL') is None
+ROWS_KERNEL = L.experiment_switch('DET6D_NO_ROWS_KERNEL') is None
 
 
 def _rows_descriptors(chains, ptr_of=None):
@@ -472,7 +472,7 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
 
 
 #: route [68 -> 64 -> 64|96 -> 128] groups through the wide register chain kernel
-CHAIN_WIDE = os.environ.get('DET6D_CHAIN_NO_WIDE') is None   # the C entry honours the same switch
+CHAIN_WIDE = L.experiment_switch('DET6D_CHAIN_NO_WIDE') is None   # the C entry honours the same switch
 
 
 def chain_eligible(lda, layers, ns):
@@ -486,7 +486,7 @@ def chain_eligible(lda, layers, ns):
 
 
 #: compact-row groups through the register chain kernels (DET6D_COMPACT_NO_CHAIN=1: three det6d_linear launches)
-COMPACT_CHAIN = os.environ.get('DET6D_COMPACT_NO_CHAIN') is None
+COMPACT_CHAIN = L.experiment_switch('DET6D_COMPACT_NO_CHAIN') is None
 
 
 def chain_compact_eligible(lda, layers):

@@ -101,7 +101,7 @@ def run_chain(x, layers, out=None, col0=0):
 #: The samplers of a layer run one after the other on the caller's stream.  Forking them onto side streams
 #: (DET6D_FORKED_SAMPLERS=1) shortens one pass by ~0.45 ms but costs throughput with many passes in flight
 #: (4121 vs 4300 scenes/s at 15 passes: more sampler workgroups resident at once, fork/join in every graph).
-SEQUENTIAL_SAMPLERS = os.environ.get('DET6D_FORKED_SAMPLERS') is None
+SEQUENTIAL_SAMPLERS = fused.L.experiment_switch('DET6D_FORKED_SAMPLERS') is None
 
 #: Grouped MLPs run on compact (ragged) row lists: a ball with cnt < nsample hits is padded by the reference with
 #: repetitions of its first cnt hits, so only the first 2^ceil(log2 cnt) slots of a centre are evaluated — the
@@ -112,7 +112,7 @@ COMPACT_ROWS = os.environ.get('DET6D_DENSE_ROWS') is None
 #: First layer of a grouped MLP from per-point partial sums (csrc/expand.hip): one plain GEMM over the N points of the
 #: layer + 3 FMAs per grouped output instead of a (3 + C)-deep GEMM over every (centre, neighbour) row; identical bits
 #: (the chain order of gathered rows puts the relative coordinates last).  DET6D_NO_EXPAND=1: the gathered GEMM instead.
-EXPAND_FIRST_LAYER = os.environ.get('DET6D_NO_EXPAND') is None
+EXPAND_FIRST_LAYER = fused.L.experiment_switch('DET6D_NO_EXPAND') is None
 
 
 class _PointnetSAModuleFSBase(nn.Module):

@@ -8,6 +8,7 @@ import time
 import numpy as np
 import torch
 
+from . import _lib as _L
 from .pcdet.config import EasyDict, cfg_from_yaml_file
 from .pcdet.models import build_network
 
@@ -270,11 +271,11 @@ class GraphedDet6D(object):
             raise NotImplementedError('graph capture needs the fused class-agnostic nms_gpu post-processing')
 
         inline = None
-        forked = os.environ.get('DET6D_FORKED_SAMPLERS') is not None      # the samplers of a layer on forked streams
+        forked = _L.experiment_switch('DET6D_FORKED_SAMPLERS') is not None      # the samplers of a layer on forked streams
         if forked and front is not None:
             raise RuntimeError("DET6D_FORKED_SAMPLERS=1 cannot be combined with a Det6DGroup (its passes take the hoisted "
                                "samplers' picks from the group's buffers)")
-        if front is None and os.environ.get('DET6D_NO_HOIST') is None and not forked:
+        if front is None and _L.experiment_switch('DET6D_NO_HOIST') is None and not forked:
             inline = _InlineHoist(model, batch_size, n_points)
 
         def body():
@@ -456,7 +457,7 @@ class Det6DGroup(object):
         self.k, self.batch_size, self.n_points = k, batch_size, n_points
         self.hi = sampler_stream
         self.plan = hoist_plan(sa_modules, n_points)
-        if os.environ.get('DET6D_NO_HOIST'):          # only the first layer's sampler ahead of the passes (round-1 behaviour)
+        if _L.experiment_switch('DET6D_NO_HOIST'):          # only the first layer's sampler ahead of the passes (round-1 behaviour)
             self.plan = self.plan[:1]
             self.plan[0]['feeds'] = False
         self.rows_all = torch.empty((nb, n_points, ld), dtype=torch.float32, device=dev)

@@ -8,10 +8,15 @@ from oracle import ops as oops
 from tests.util import make_batch
 oops.build()
 
+FALLBACK = 'fallback' in sys.argv     # a plain (b, n) float scratch instead of the cooperative workspace: memory-resident kernel
+
+
 def check(xyz, m, tag):
     x = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
     idx = torch.full((xyz.shape[0], m), -7, dtype=torch.int32, device='cuda')
     ws = fused.fps_workspace(xyz.shape[0], xyz.shape[1])
+    if FALLBACK:
+        ws = torch.empty((xyz.shape[0] * xyz.shape[1] * 4,), dtype=torch.uint8, device='cuda')
     fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0, temp=ws); torch.cuda.synchronize()
     t0 = time.perf_counter()
     fused.fps_fused(x, 0, xyz.shape[1], m, None, 1.0, idx, 0, temp=ws); torch.cuda.synchronize()
@@ -23,7 +28,7 @@ def check(xyz, m, tag):
 
 allok = True
 rng = np.random.default_rng(0)
-if os.environ.get('DET6D_FPS_COOP') == '0':      # the memory-resident fallback: two short cases
+if FALLBACK:      # the memory-resident fallback: two short cases
     allok &= check(make_batch(31, 2, 65536, dup_frac=0.1)[..., :3], 600, 'fallback scenes 2 x 65536')
     allok &= check(make_batch(33, 1, 32768, dup_frac=0.3)[..., :3], 400, 'fallback scenes 1 x 32768')
     print('ALL', allok)

@@ -246,7 +246,10 @@ def test_compact_mlp_equals_dense_oracle(oracle_ops, c_in, widths, ns, chain, sm
     ({'DET6D_NO_HOIST': '1'}, 'pass_group or two_stage or graph_replay')])
 def test_model_parity_on_the_other_row_paths(env, select):
     """the whole-model bit-exact tests run on compact rows with the fused kernels by default; rerun subsets on the
-    reference's dense row space and on every alternative route (switches are read at import: child process)"""
+    reference's dense row space (DET6D_DENSE_ROWS: a switch of the shipped library) and on every alternative route of the
+    experiments build (DET6D_EXPERIMENTS_LIB=1; switches are read at import: child process)"""
+    if set(env) != {'DET6D_DENSE_ROWS'}:
+        env = dict(env, DET6D_EXPERIMENTS_LIB='1')
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_model_gpu.py'), '-q', '-x', '-m', 'gpu',
                           '-k', select], env=dict(os.environ, **env), cwd=ROOT, capture_output=True,
                          text=True, timeout=900)
@@ -299,7 +302,7 @@ def test_plain_layer_stacks_other_tiles(rb):
         pytest.skip('already a child')
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
                           'test_plain_layer_stacks_equal_the_layer_by_layer_oracle'],
-                         env=dict(os.environ, DET6D_ROWS_RB=rb), cwd=ROOT, capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, DET6D_ROWS_RB=rb, DET6D_EXPERIMENTS_LIB='1'), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout
 
@@ -314,7 +317,7 @@ def test_group_kernel_other_forms(env):
         pytest.skip('already a child')
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
                           'test_group_kernel_equals_dense_oracle or test_group_kernel_on_degenerate_lists'],
-                         env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, DET6D_EXPERIMENTS_LIB='1', **env), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'passed' in out.stdout
 

@@ -327,20 +327,22 @@ def test_fused_sampler_and_helpers(ext, oracle_ops):
     np.testing.assert_array_equal(xyz2.cpu().numpy(), oxyz2)
 
 
-@pytest.mark.parametrize("skip", ["16", "162", "8", "0"])
-def test_pruned_fps_kernels_are_exact(skip):
-    """fps_cells.hip: the wave-skip sampler (default for 16384 points: 16 waves x 16 slots; 8 x 32 variant) and
-    the cell sampler (DET6D_FPS_SKIP=0 + DET6D_FPS_CELLS_MIN_N) must give the oracle's picks bit for bit,
-    duplicates and all-equal clouds included"""
+def test_pruned_fps_kernel_is_exact():
+    """fps_cells.hip: the wave-skip sampler (16384 points: 16 waves x 16 slots on k-d regions) gives the oracle's picks bit
+    for bit, duplicates and all-equal clouds included; the other sizes of the script run the fat-thread kernels"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DET6D_FPS_CELLS_MIN_N="4096", DET6D_FPS_SKIP=skip)
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_cells.py")], env=env,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_cells.py")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "exact" in l]
     assert len(lines) == 7 and all("exact=True" in l or "exact True" in l for l in lines), out.stdout
+    # the 16384-point suites of the round-4 sampler work: ray-cast scenes, every point twice, a lattice of exact ties, far
+    # outliers, 32 scenes, m = n
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_seq.py")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ALL EXACT" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_skip_sampler_on_adversarial_clouds():
@@ -404,7 +406,7 @@ def test_group_expand_equals_the_gathered_first_layer(ext, oracle_ops, lda, c1):
 def test_cooperative_sampler_for_large_scenes():
     """csrc/fps_coop.hip: D-FPS of 32768 / 65536-point scenes held in registers by 2 / 4 cooperating workgroups per scene
     (BASELINE config 5): the oracle's picks bit for bit, ties / duplicates / odd batch sizes included; and the
-    memory-resident fallback (DET6D_FPS_COOP=0) still agrees; so does the opt-in same-XCD fast path"""
+    memory-resident fallback (a scratch too small for the cooperative workspace) still agrees; so does the opt-in same-XCD fast path"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -413,8 +415,8 @@ def test_cooperative_sampler_for_large_scenes():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout, out.stdout
     print(out.stdout)
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py")], capture_output=True, text=True,
-                         timeout=900, env=dict(os.environ, DET6D_FPS_COOP="0"))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py"), "fallback"], capture_output=True,
+                         text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout and "fallback" in out.stdout, out.stdout
     # DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the round-0 handshake allow (the
@@ -517,7 +519,7 @@ def test_fallback_kernels_via_env_switches(tmp_path):
     environment switches in a child process and rerun the parity tests that cover them"""
     import subprocess
     import sys
-    env = dict(os.environ, DET6D_LINEAR_NO_FAST='1', DET6D_CHAIN_LDS='1', DET6D_CHAIN_NO_WIDE='1')
+    env = dict(os.environ, DET6D_EXPERIMENTS_LIB='1', DET6D_LINEAR_NO_FAST='1', DET6D_CHAIN_LDS='1', DET6D_CHAIN_NO_WIDE='1')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_ops_gpu.py'), '-q', '-x', '-m', 'gpu',
                           '-k', 'test_linear or (chain3 and not widths4 and not widths5 and not widths6 and not widths7)'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
