@@ -29,10 +29,10 @@ namespace {
 typedef unsigned long long u64;
 typedef float sq_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kCand = 4;                 // candidates per record = sequencer lanes per region
+constexpr int kCandMax = 4;              // candidates per record = sequencer lanes per region (2 or 4)
 constexpr int kWaves = 16, kSlots = 16;  // 16 x 64 x 16 = 16384 points
 constexpr int kMaxPicks = 16;            // picks per round at most
-static_assert(kWaves * kCand == 64, "one sequencer lane per candidate");
+static_assert(kWaves * kCandMax == 64, "one sequencer lane per candidate");
 
 __device__ __forceinline__ unsigned sq_bitrev_bits(unsigned v, int bits) {
   return bits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));
@@ -94,6 +94,23 @@ __device__ __forceinline__ float sq_quad_max(float a) {
       : "=&v"(r)
       : "v"(a));
   return r;
+}
+
+// max over the lanes of every PAIR (lanes 2p, 2p+1)
+__device__ __forceinline__ float sq_pair_max(float a) {
+  float r;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "=&v"(r)
+      : "v"(a));
+  return r;
+}
+template <int K>
+__device__ __forceinline__ float sq_group_max(float a) {
+  if constexpr (K == 2) return sq_pair_max(a);
+  else return sq_quad_max(a);
 }
 
 // max over the 64 lanes of an unsigned value (uniform result)
@@ -179,7 +196,7 @@ __device__ __forceinline__ void sq_apply(float cx, float cy, float cz, const flo
 // and the lane that holds a candidate writes it to the record itself.  A lane knows only its two best points, so the list
 // ends with the first candidate that is a lane's SECOND (what is left in that lane is ordered after it, but not necessarily
 // after later heads).  Returns the region's maximum.
-template <int SG>
+template <int SG, int kCand>
 __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log2s, const float (&px)[SG], const float (&py)[SG],
                                            const float (&pz)[SG], float (&pt)[SG], const unsigned short *korig_w, SqRecords &rec,
                                            int wave) {
@@ -209,9 +226,14 @@ __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log
   }
   static_assert(SG % 2 == 0, "slot pairs");
   auto second_slot = [&]() -> int {                      // lowest slot != bs holding the lane's second value
+    // (rare path.  The value searched for goes through an opaque asm so that the 16-step search stays inside the branch that
+    // needs it: left alone, the compiler hoists it in front of the candidate loop of EVERY rescan)
+    float target = sec;
+    int skip = bs;
+    asm volatile("" : "+v"(target), "+v"(skip));
     int ss = 0;
 #pragma unroll
-    for (int j = SG - 1; j >= 0; --j) ss = (pt[j] == sec && j != bs) ? j : ss;
+    for (int j = SG - 1; j >= 0; --j) ss = (pt[j] == target && j != skip) ? j : ss;
     return ss;
   };
 
@@ -243,7 +265,7 @@ __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log
     if (lane == wl) {                                      // the holder writes its candidate
       float x, y, z;
       sq_select<0, SG>(ws, px, py, pz, x, y, z);
-      const int o = wave * kCand + i;
+      const int o = wave * kCandMax + i;
       rec.v[o] = wm;
       rec.k[o] = (int)korig_w[lane * SG + ws];
       rec.x[o] = x; rec.y[o] = y; rec.z[o] = z;
@@ -269,6 +291,7 @@ __device__ unsigned long long d6_fps_seq_stats[16];
 
 // One workgroup of 16 waves per scene.  `perm`: the scene's Morton permutation whose lane groups of 16 consecutive positions
 // are ordered by tie key (fps_cells.hip: cell_sort_kernel + skip_group_order_kernel<16>).
+template <int kCand>
 __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
                                                        int idx_add, const float *__restrict__ xyz,
                                                        const int *__restrict__ perm, int *__restrict__ idxs, int max_picks) {
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
         }
         const int i = __builtin_ctzll(need);
         SQ_STAT(2, 1);
-        cmax = sq_rescan<SG>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave);
+        cmax = sq_rescan<SG, kCand>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave);
       }
     }
     if (r >= m) break;                                    // (uniform over the workgroup: r is advanced by pick_n everywhere)
@@ -357,14 +380,17 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
     // ---- B. wave 0: as many picks as the records allow
     if (wave == 0) {
       SQ_STAT(0, 1);
-      const int nc = rec.nc[lane >> 2];
-      const int slot = lane & 3;
-      float cv = slot < nc ? rec.v[lane] : -1.0f;         // current value of this candidate (-1: no candidate in this slot)
-      const float qx = rec.x[lane], qy = rec.y[lane], qz = rec.z[lane];
-      const int kidx = rec.k[lane];
-      const bool is_last = slot == nc - 1;
-      float bound_v, dummy;                               // value of the record's last candidate (quad-uniform)
-      sq_quad_max2(is_last ? cv : -2.0f, 0.f, bound_v, dummy);
+      constexpr int LOG2K = kCand == 2 ? 1 : 2;
+      const bool live = lane < kWaves * kCand;
+      const int region = live ? lane >> LOG2K : 0;
+      const int nc = rec.nc[region];
+      const int slot = lane & (kCand - 1);
+      const int o = region * kCandMax + slot;             // records keep the stride of four
+      float cv = live && slot < nc ? rec.v[o] : -1.0f;    // current value of this candidate (-1: no candidate in this slot)
+      const float qx = rec.x[o], qy = rec.y[o], qz = rec.z[o];
+      const int kidx = rec.k[o];
+      const bool is_last = live && slot == nc - 1;
+      const float bound_v = sq_group_max<kCand>(is_last ? cv : -2.0f);   // value of the record's last candidate (group-uniform)
       int j = 0;
       const int jmax = min(max_picks, m - r);
       for (; j < jmax; ++j) {
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
         // or one ordered before it; an equal value reached by coincidence counts as unknown: the round ends, the region is
         // rescanned — the pick that lowered its last candidate passes its box test — and is fresh in the next one).
         const float pe = (cv > bound_v || (is_last && cv == bound_v)) ? 1.0f : 0.0f;
-        const bool exact = sq_quad_max(pe) != 0.0f;
+        const bool exact = sq_group_max<kCand>(pe) != 0.0f;
         // ONE reduction decides both questions: key = 2 * bits(value) + (1 for the bound of an unknown region, 0 for a
         // candidate of an exact one); values are >= +0, so their bits order like the values and fit 31 bits; an empty slot
         // (-1) has key 0, below the key 2 of a zero value.  The largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends.
@@ -422,8 +448,12 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, l
                          int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream) {
   if (n != 16384) return DET6D_EINVAL;
   (void)regions_per_wave;
-  static const int max_picks = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
-  hipLaunchKernelGGL(fps_seq_kernel, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx,
-                     max_picks < 1 ? 1 : max_picks > kMaxPicks ? kMaxPicks : max_picks);
+  static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
+  static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
+  const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
+  if (cands == 2)
+    hipLaunchKernelGGL(fps_seq_kernel<2>, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+  else
+    hipLaunchKernelGGL(fps_seq_kernel<4>, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
   return det6d_check_launch("det6d_fps (multi-pick)");
 }
