@@ -1,33 +1,36 @@
 // fps_coop.hip — farthest point sampling (D-FPS) of clouds too large for one CU's register file
 // (N = 32768 / 65536: BASELINE.json configs[4], the 65536-point scenes), bit for bit the picks of
-// farthest_point_sampling_kernel (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222, tie order
-// of its shared-memory tree :94-99,159-216).
+// farthest_point_sampling_kernel (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222, tie order of its
+// shared-memory tree :94-99,159-216).
 //
-// The memory-resident fallback (fps.hip: fps_mem_kernel) re-reads all N points from L2 every round: 111 us per round
-// on MI355X, 1.8 s for the 16383 rounds of a 65536-point scene.  Here a scene is held IN REGISTERS by PARTS = N / 16384
-// cooperating workgroups (one per CU): the scene is sorted along a Morton curve (device radix sort over all scenes of
-// the launch, key = scene | 20-bit Morton code), part q keeps sorted positions [q * 16384, (q+1) * 16384) exactly like
-// the wave-skip sampler of fps_cells.hip (16 waves x 16 points per lane, one bounding box per wave, cached arg-max,
-// exact floating-point skip test, explicit tie paths).  Per round every part reduces to ITS best candidate as before
-// (one workgroup barrier), publishes it in a 40-byte global slot, and every wave of every part polls the PARTS slots
-// of the round and takes the global arg-max under the reference's tie key — no second barrier, no host involvement.
+// The memory-resident fallback (fps.hip: fps_mem_kernel) re-reads all N points from L2 every pick: 111 us per pick on MI355X,
+// 1.8 s for the 16383 picks of a 65536-point scene.  Here a scene is held IN REGISTERS by PARTS = N / 16384 cooperating
+// workgroups (one per CU): the scene is sorted along a Morton curve (device radix sort over all scenes of the launch, key =
+// scene | 20-bit Morton code), part q keeps sorted positions [q * 16384, (q+1) * 16384) as 16 waves x 16 points per lane, one
+// bounding box per wave, exact floating-point skip test, explicit tie paths — the wave-skip sampler of fps_cells.hip.
+//
+// Shipped form: MULTI-PICK rounds (fps_coop_multi_kernel; decision rule and its executable model: fps_seq.hip,
+// tests/models/fps_lookahead.py).  Per round every wave applies the round's picks to its points and republishes its top 4
+// points in LDS when they could change; wave 0 of every part publishes the part's 64 candidates as tagged 8-byte words, gathers
+// the candidates of all parts and decides as many picks as the rule allows (24-28 per round on the benchmark scenes, cap 64);
+// every part takes the same decisions from the same words, so one L2 round trip serves a whole round.  0.85 us per pick
+// against 1.63 for the one-pick form (rounds 2-3, experiments build: DET6D_FPS_COOP_MULTI=0), which exchanged one candidate
+// per part and per pick.
 //
 // Exchange protocol (no fences: every 8-byte word carries its own round tag):
-//   slot(scene, parity, part) = 5 words {payload, tag}: value, original index, x, y, z.  Words are written / read with
-//   relaxed agent-scope 64-bit atomics (sc1: visible across XCDs); a reader accepts a slot when all five tags equal
-//   the round.  Two parities suffice: a part that writes round r+1 has read every slot of round r, so every part has
-//   written round r and is done reading round r-1.  The area is zeroed by the key kernel of the same launch (stream
-//   order), tags are round numbers >= 1.
-// Placement: block ids of one scene are congruent mod 8, i.e. on one XCD under round-robin dispatch (speed only).
+//   words are written / read with relaxed 64-bit atomics; a reader accepts a candidate when its five tags equal the round.
+//   Two parities suffice: a part that writes round r+1 has read every word of round r, so every part has written round r and
+//   is done reading round r-1.  The area is zeroed by the key kernel of the same launch (stream order), tags are >= 1.
 // Publishing stores are AGENT scope (the HIP memory model's guarantee that another workgroup's agent-scope load sees them).
 // DET6D_FPS_COOP_FAST=1 allows a part to publish with workgroup-scope stores — they stay in the XCD's L2 instead of being
-// written through to the fabric: 1.63 -> 1.40 us per round — when (a) all parts of its scene report the same HW_REG_XCC_ID
-// and (b) a handshake in round 0 has shown, on this device and this placement, that a workgroup-scope store of every part
-// reaches the other parts' agent-scope loads; a part that fails either test keeps agent scope (mixing is fine: readers
-// always load with agent scope).
-// A part that waits longer than ~2 s for a partner (it can only be a scheduling accident) raises the error word of
-// the workspace and leaves: det6d_fps_fused_status reports the launch as failed instead of the GPU hanging.
-#include "common.h"
+// written through to the fabric — when (a) all parts of its scene report the same HW_REG_XCC_ID and (b) a handshake in round
+// 0 has shown, on this device and this placement, that a workgroup-scope store of every part reaches this part's
+// agent-scope loads; a part that fails either test keeps agent scope (mixing is fine: readers always load with agent scope).
+// Placement: block ids of one scene are congruent mod 8, i.e. on one XCD under round-robin dispatch (speed only).
+// A part that waits longer than ~2 s for a partner (it can only be a scheduling accident) raises the error word of the
+// workspace, completes the scene's picks with a valid index and leaves: det6d_fps_fused_status reports the launch as failed
+// instead of the GPU hanging.
+#include "fps_multi.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -35,6 +38,10 @@ namespace {
 
 constexpr int kPartPoints = 16384;
 constexpr int kSlotWords = 8;   // 5 used, padded to 64 bytes
+constexpr int kMultiCands = 4;  // candidates per wave record of the multi-pick kernel
+
+// 64-bit words of one scene's exchange area in the multi-pick kernel: round-0 words + two parities of candidate words
+__host__ __device__ constexpr size_t coop_multi_words(int parts, int k) { return (size_t)8 * parts + (size_t)2 * parts * 16 * k * 5; }
 
 __device__ __forceinline__ unsigned co_bitrev_bits(unsigned v, int bits) {
   return bits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));
@@ -136,6 +143,7 @@ __device__ __forceinline__ unsigned long long co_pack(unsigned payload, unsigned
   return ((unsigned long long)tag << 32) | payload;
 }
 
+#ifdef DET6D_EXPERIMENTS   // the one-pick form (rounds 2-3): kept for A/B runs, DET6D_FPS_COOP_MULTI=0
 template <int PARTS>
 __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int log2s, long long xyz_bstride,
                                                         long long idx_bstride, int idx_add, const float *__restrict__ xyz,
@@ -329,6 +337,261 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int n, int m, int
   }
 }
 
+#endif  // DET6D_EXPERIMENTS
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Multi-pick form.  The kernel above pays one L2 exchange (0.55 us agent scope) and one rescan on the critical path of EVERY
+// pick.  Here a round is: (A) every wave applies the picks of the last round to its 1024 points and, if they could change
+// anything, rewrites its record — its top K points in the reference's order — in LDS; (B) wave 0 of every part publishes the
+// part's 16 K candidates as tagged 8-byte words, polls the candidates of ALL parts of the scene, and decides as many picks as
+// the records allow with the rule of fps_seq.hip (the best exact candidate, provided every unknown region's bound is strictly
+// below it).  Every part runs the same decisions on the same records, so the picks need no second exchange: one L2 round trip
+// per ROUND, typically 8-12 picks.  Sequencer lane l holds candidate l of set s = 0 .. SETS-1 (global candidate 64 s + l;
+// a wave's K candidates are K neighbouring lanes of one set).
+template <int PARTS, int K>
+__global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int m, int log2s, long long xyz_bstride,
+                                                              long long idx_bstride, int idx_add, const float *__restrict__ xyz,
+                                                              const unsigned *__restrict__ perm, int *__restrict__ idxs,
+                                                              unsigned long long *__restrict__ exch, int *err, int allow_fast,
+                                                              int max_picks) {
+  constexpr int SG = kSlots;
+  constexpr int CPP = kWaves * K;                       // candidates per part
+  constexpr int SETS = PARTS * CPP / 64;                // candidates per sequencer lane
+  constexpr int LOG2K = K == 2 ? 1 : 2;
+  static_assert(K == 2 || K == 4, "candidates per record");
+  static_assert(SETS >= 1 && SETS * 64 == PARTS * CPP, "whole sets");
+  __shared__ unsigned short korig[64 * kWaves * kSlots];
+  __shared__ SqRecords rec;
+  __shared__ float pick_x[kCoopMaxPicks], pick_y[kCoopMaxPicks], pick_z[kCoopMaxPicks];
+  __shared__ int pick_n, abort_flag;
+  const int h = threadIdx.x, lane = h & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(h >> 6);
+  // block -> (scene, part): the parts of a scene sit on block ids congruent mod 8 (one XCD under round-robin dispatch)
+  const int t_ = blockIdx.x >> 3;
+  const int part = t_ % PARTS;
+  const int scene = (t_ / PARTS) * 8 + (blockIdx.x & 7);
+  if (scene >= b) return;
+  xyz += (size_t)scene * xyz_bstride;
+  perm += (size_t)scene * n + (size_t)part * kPartPoints;
+  idxs += (size_t)scene * idx_bstride;
+  // exchange area of the scene: [8 * PARTS] round-0 words, then [2 parities][PARTS][CPP][5] candidate words
+  exch += (size_t)scene * coop_multi_words(PARTS, K);
+  unsigned long long *slots = exch + 8 * PARTS;
+  unsigned short *korig_w = korig + (size_t)wave * 64 * SG;
+
+  float px[SG], py[SG], pz[SG], pt[SG];
+  float lox, loy, loz, hix, hiy, hiz;
+  {
+    float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+      const int pos = (wave * 64 + lane) * SG + j;
+      const int k = (int)perm[pos];
+      korig[pos] = (unsigned short)k;
+      px[j] = xyz[(size_t)k * 3 + 0];
+      py[j] = xyz[(size_t)k * 3 + 1];
+      pz[j] = xyz[(size_t)k * 3 + 2];
+      asm volatile("" : "+v"(px[j]), "+v"(py[j]), "+v"(pz[j]));
+      pt[j] = 1e10f;
+      ax = d6_vmin(ax, px[j]); bx = d6_vmax(bx, px[j]);
+      ay = d6_vmin(ay, py[j]); by = d6_vmax(by, py[j]);
+      az = d6_vmin(az, pz[j]); bz = d6_vmax(bz, pz[j]);
+    }
+    lox = d6_wave_min(ax); hix = d6_wave_max(bx);
+    loy = d6_wave_min(ay); hiy = d6_wave_max(by);
+    loz = d6_wave_min(az); hiz = d6_wave_max(bz);
+  }
+  float cmax = __builtin_inff();
+  if (h == 0) { pick_x[0] = xyz[0]; pick_y[0] = xyz[1]; pick_z[0] = xyz[2]; pick_n = 1; abort_flag = 0; }
+  if (part == 0 && h == 0) idxs[0] = idx_add;             // the first pick is point 0 (sampling_gpu.cu:131-133)
+
+  // Round 0 (wave 0): placement + visibility handshake for the optional workgroup-scope publishing stores, as in the
+  // one-pick kernel above
+  bool fast = false;
+  if (wave == 0 && allow_fast) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+    const bool reader0 = lane < PARTS;
+    if (lane == 0) {
+      __hip_atomic_store(exch + (size_t)part * 8 + 0, co_pack(xcc, 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(exch + (size_t)part * 8 + 1, co_pack(0x5A5A0000u | (unsigned)part, 0x7ffffffeu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const unsigned long long *th = exch + (size_t)(reader0 ? lane : 0) * 8;
+    bool seen = false;
+    unsigned long long w0 = 0ull;
+    for (int spins = 0; spins < 8192 && !seen; ++spins) {
+      w0 = __hip_atomic_load(th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long w1 = __hip_atomic_load(th + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seen = __ballot(reader0 && ((unsigned)(w0 >> 32) != 0x7fffffffu || (unsigned)(w1 >> 32) != 0x7ffffffeu)) == 0ull;
+      if (!seen) __builtin_amdgcn_s_sleep(1);
+    }
+    fast = seen && __ballot(reader0 && (unsigned)w0 != xcc) == 0ull;    // (a part that does not see all tokens stays on agent scope)
+  }
+  __syncthreads();
+
+  int r = 1;                                              // picks made so far
+  for (unsigned round = 1;; ++round) {
+    // ---- A. every wave: the picks of the last round against its points
+    {
+      const int np = pick_n;
+      const float sx = pick_x[lane], sy = pick_y[lane], sz = pick_z[lane];
+      const float gx = fmaxf(0.f, fmaxf(lox - sx, sx - hix));
+      const float gy = fmaxf(0.f, fmaxf(loy - sy, sy - hiy));
+      const float gz = fmaxf(0.f, fmaxf(loz - sz, sz - hiz));
+      const float lb = d6_sqdist(gx, gy, gz);
+      u64 need = __ballot(lane < np && !(lb >= cmax));
+      if (need != 0ull) {
+        while (need & (need - 1ull)) {
+          const int i = __builtin_ctzll(need);
+          need &= need - 1ull;
+          sq_apply<SG>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), px, py, pz, pt);
+        }
+        const int i = __builtin_ctzll(need);
+        cmax = sq_rescan<SG, K>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave);
+      }
+    }
+    if (r >= m || abort_flag) break;
+    __syncthreads();                                      // the part's records are complete
+    // ---- B. wave 0: publish, gather the scene's records, decide
+    if (wave == 0) {
+      unsigned long long *mine = slots + ((size_t)(round & 1) * PARTS + part) * CPP * 5;
+      if (lane < CPP) {
+        const int w = lane >> LOG2K, c = lane & (K - 1);
+        const int o = w * kCandMax + c;
+        const unsigned kword = (unsigned)rec.k[o] | ((unsigned)rec.nc[w] << 16);
+        unsigned long long *d = mine + (size_t)lane * 5;
+        const unsigned long long w0 = co_pack(__builtin_bit_cast(unsigned, rec.v[o]), round), w1 = co_pack(kword, round),
+                                 w2 = co_pack(__builtin_bit_cast(unsigned, rec.x[o]), round),
+                                 w3 = co_pack(__builtin_bit_cast(unsigned, rec.y[o]), round),
+                                 w4 = co_pack(__builtin_bit_cast(unsigned, rec.z[o]), round);
+        if (fast) {
+          __hip_atomic_store(d + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(d + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(d + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(d + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(d + 4, w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          __hip_atomic_store(d + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(d + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(d + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(d + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(d + 4, w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // gather: global candidate 64 s + lane = candidate (64 s + lane) % CPP of part (64 s + lane) / CPP
+      float cv[SETS], qx[SETS], qy[SETS], qz[SETS], bound_v[SETS];
+      int kidx[SETS];
+      bool is_last[SETS];
+      bool dead = false;
+      const unsigned long long *base = slots + (size_t)(round & 1) * PARTS * CPP * 5;
+#pragma unroll
+      for (int s_ = 0; s_ < SETS; ++s_) {
+        const unsigned long long *src = base + (size_t)(64 * s_ + lane) * 5;
+        unsigned long long w0, w1, w2, w3, w4;
+        int spins = 0;
+        for (;;) {
+          w0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w3 = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w4 = __hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool ok = (unsigned)(w0 >> 32) == round && (unsigned)(w1 >> 32) == round && (unsigned)(w2 >> 32) == round &&
+                          (unsigned)(w3 >> 32) == round && (unsigned)(w4 >> 32) == round;
+          if (__ballot(!ok) == 0ull) break;
+          if (++spins > (1 << 21)) { dead = true; break; }   // ~2 s: a partner never arrived
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (dead) break;
+        const int nc = (int)(((unsigned)w1 >> 16) & 7u);
+        const int slot = lane & (K - 1);
+        cv[s_] = slot < nc ? __builtin_bit_cast(float, (unsigned)w0) : -1.0f;
+        kidx[s_] = (int)((unsigned)w1 & 0xFFFFu);
+        qx[s_] = __builtin_bit_cast(float, (unsigned)w2);
+        qy[s_] = __builtin_bit_cast(float, (unsigned)w3);
+        qz[s_] = __builtin_bit_cast(float, (unsigned)w4);
+        is_last[s_] = slot == nc - 1;
+        bound_v[s_] = sq_group_max<K>(is_last[s_] ? cv[s_] : -2.0f);
+      }
+      int j = 0;
+      if (dead) {
+        if (lane == 0) { atomicExch(err, 1); abort_flag = 1; }
+        if (part == 0) for (int i = r + lane; i < m; i += 64) idxs[i] = idx_add;   // in-range picks: nothing downstream may fault
+      } else {
+        // per-round constants of every candidate: ntk = ~tie key (larger wins), thr = the smallest value that makes its region
+        // exact when THIS candidate holds it (the bound itself for the record's last candidate, the next float above it for the
+        // others), ubkey = the key of the region's bound when it is unknown
+        unsigned ntk[SETS], ubkey[SETS];
+        float thr[SETS];
+        bool deadc[SETS];
+#pragma unroll
+        for (int s_ = 0; s_ < SETS; ++s_) {
+          ntk[s_] = ~sq_tie_key(kidx[s_], log2s);
+          deadc[s_] = cv[s_] < 0.f;
+          const float bv = bound_v[s_];
+          thr[s_] = is_last[s_] ? bv : __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bv) + (bv >= 0.f ? 1u : 0u));
+          ubkey[s_] = bv < 0.f ? 0u : ((__builtin_bit_cast(unsigned, bv) << 1) | 1u) + 2u;
+        }
+        const int jmax = min(max_picks, m - r);
+        for (; j < jmax; ++j) {
+          float pe[SETS], ge[SETS];
+#pragma unroll
+          for (int s_ = 0; s_ < SETS; ++s_) pe[s_] = cv[s_] >= thr[s_] ? 1.0f : 0.0f;
+          sq_group_max_n<K, SETS>(pe, ge);
+          // this lane's best (key, ~tie key) over its sets as one 64-bit number
+          u64 lbest = 0ull;
+          int lset = 0;
+#pragma unroll
+          for (int s_ = 0; s_ < SETS; ++s_) {
+            const unsigned ekey = deadc[s_] ? 0u : (__builtin_bit_cast(unsigned, cv[s_]) << 1) + 2u;
+            const unsigned key = ge[s_] != 0.0f ? ekey : ubkey[s_];
+            const u64 comp = ((u64)key << 32) | ntk[s_];
+            const bool better = comp > lbest;
+            lset = better ? s_ : lset;
+            lbest = better ? comp : lbest;
+          }
+          const unsigned lkey = (unsigned)(lbest >> 32);
+          const unsigned best = sq_wave_max_u32(lkey);
+          if (best & 1u) break;                              // an unknown region may hold the maximum: the round ends
+          int kk = kidx[0];
+          float ex = qx[0], ey = qy[0], ez = qz[0];
+#pragma unroll
+          for (int s_ = 1; s_ < SETS; ++s_) {
+            const bool sel = lset == s_;
+            kk = sel ? kidx[s_] : kk; ex = sel ? qx[s_] : ex; ey = sel ? qy[s_] : ey; ez = sel ? qz[s_] : ez;
+          }
+          const u64 tie = __ballot(lkey == best);
+          int wl = __builtin_ctzll(tie);
+          if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~(unsigned)lbest);
+          if (lane == wl) {
+            pick_x[j] = ex; pick_y[j] = ey; pick_z[j] = ez;
+            if (part == 0) idxs[r + j] = kk + idx_add;
+          }
+          const float sx = d6_readlane_f(ex, wl), sy = d6_readlane_f(ey, wl), sz = d6_readlane_f(ez, wl);
+          if constexpr (SETS % 2 == 0) {
+            const sq_f32x2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
+#pragma unroll
+            for (int s_ = 0; s_ < SETS; s_ += 2) {
+              const sq_f32x2 dx = sq_f32x2{qx[s_], qx[s_ + 1]} - c2x;
+              const sq_f32x2 dy = sq_f32x2{qy[s_], qy[s_ + 1]} - c2y;
+              const sq_f32x2 dz = sq_f32x2{qz[s_], qz[s_ + 1]} - c2z;
+              sq_f32x2 d = dy * dy;
+              d = __builtin_elementwise_fma(dx, dx, d);
+              d = __builtin_elementwise_fma(dz, dz, d);
+              cv[s_] = d6_vmin(cv[s_], d[0]);
+              cv[s_ + 1] = d6_vmin(cv[s_ + 1], d[1]);
+            }
+          } else {
+#pragma unroll
+            for (int s_ = 0; s_ < SETS; ++s_) cv[s_] = d6_vmin(cv[s_], d6_sqdist(qx[s_] - sx, qy[s_] - sy, qz[s_] - sz));
+          }
+        }
+      }
+      if (lane == 0) pick_n = j;
+    }
+    __syncthreads();                                      // picks published
+    r += pick_n;
+  }
+}
+
 struct CoopLayout {
   size_t keys_in, keys_out, vals_in, vals_out, cub, exch, err, total;
   size_t cub_bytes;
@@ -355,7 +618,7 @@ CoopLayout coop_layout(int b, int n) {
   L.vals_in = off; off = align(off + items * 4);
   L.vals_out = off; off = align(off + items * 4);
   L.cub = off; off = align(off + cub);
-  L.exch = off; off = align(off + (size_t)b * 2 * 4 * kSlotWords * 8);
+  L.exch = off; off = align(off + (size_t)b * coop_multi_words(4, kMultiCands) * 8);    // (covers the one-pick kernel's 2 x 4 x 8 words too)
   L.total = off;
   return L;
 }
@@ -382,8 +645,9 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   unsigned long long *exch = (unsigned long long *)(ws + L.exch);
   int *err = (int *)(ws + L.err);
   const int parts = n / kPartPoints;
-  hipLaunchKernelGGL(coop_keys_kernel, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, keys_in, vals_in, exch,
-                     2 * parts * kSlotWords, err);
+  static const int multi = det6d_env_int("DET6D_FPS_COOP_MULTI", 1);      // experiments build: 0 = the one-pick kernel
+  const int exch_words = multi ? (int)coop_multi_words(parts, kMultiCands) : 2 * parts * kSlotWords;
+  hipLaunchKernelGGL(coop_keys_kernel, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, keys_in, vals_in, exch, exch_words, err);
   size_t cub = L.cub_bytes;
   const hipError_t sort_rc = hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub, keys_in, keys_out, vals_in, vals_out,
                                                                 (unsigned)((size_t)b * n), 0, 20 + scene_bits(b), stream);
@@ -396,6 +660,17 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   const int grid = 8 * parts * ((b + 7) / 8);
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
+  static const int max_picks = det6d_env_int("DET6D_FPS_SEQ_PICKS", kCoopMaxPicks);
+  if (multi) {
+    if (parts == 4)
+      hipLaunchKernelGGL((fps_coop_multi_kernel<4, kMultiCands>), dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, xyz, vals_out, idx, exch, err, allow_fast, max_picks);
+    else
+      hipLaunchKernelGGL((fps_coop_multi_kernel<2, kMultiCands>), dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride,
+                         idx_add, xyz, vals_out, idx, exch, err, allow_fast, max_picks);
+    return det6d_check_launch("det6d_fps (cooperative, multi-pick)");
+  }
+#ifdef DET6D_EXPERIMENTS
   if (parts == 4)
     hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
                        vals_out, idx, exch, err, allow_fast);
@@ -403,6 +678,9 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
     hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
                        vals_out, idx, exch, err, allow_fast);
   return det6d_check_launch("det6d_fps (cooperative)");
+#else
+  return DET6D_EINVAL;
+#endif
 }
 
 // byte offset of the (sticky) error word inside a cooperative workspace
