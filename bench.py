@@ -39,8 +39,11 @@ path; RCCL is used only for the barrier and the max-over-ranks of the window tim
 prints ONE JSON line.  N = 1 without `--worker`: an orchestrating parent that never touches the GPU starts the
 measuring worker and then the extra legs (dense rows, the other BASELINE configurations, ray-cast LiDAR scenes) as
 processes of their own, one at a time, and prints the merged line.  Every leg that runs on other scenes or rows (dense rows,
-ray-cast scenes) reports its own GEMM-family roofline; `latency_under_load` is the per-step issue -> in-order delivery time
-with the pipeline full; `h2d_inclusive` the same stream of steps with every batch uploaded from pinned host memory.
+ray-cast scenes, 65536-point scenes) reports its own GEMM-family roofline, the 65536-point leg its samplers' us per pick as well
+(`fps_us_per_round`); the ray-cast leg's rate and roofline fraction are repeated in `config.raycast_scenes_per_s` /
+`roofline.raycast` (both density regimes in the part of the line the driver parses); `latency_under_load` is the per-step
+issue -> in-order delivery time with the pipeline full; `latency_b1` ONE frame on an idle chip (the reference's single-frame
+callers); `h2d_inclusive` the same stream of steps with every batch uploaded from pinned host memory.
 
 The measuring legs other than the timed region live in bench_legs.py.
 """

@@ -1,19 +1,25 @@
-"""Executable model of the look-ahead farthest point sampler (de6d_amd/csrc/fps_seq.hip).
+"""Executable model of the multi-pick decision rule of the farthest point samplers (de6d_amd/csrc/fps_coop.hip, shipped:
+the 32768 / 65536-point cooperative sampler; de6d_amd/csrc/fps_seq.hip, experiments build: one workgroup per 16384-point
+scene; shared pieces in csrc/fps_multi.h).
 
-TEST INFRASTRUCTURE: a discrete-event simulation of the kernel's protocol under a RANDOM schedule, checked against a
-plain sequential restatement of farthest_point_sampling_kernel (sampling_gpu.cu:101-222: arg-max of the running
-min-distances, ties to the smallest (bitrev_{log2 S}(k mod S), k)).  It exists to show that the decision rule is SOUND
-whatever the interleaving of its agents is: a sequencer that only ever sees published top-2 records of the regions and
-never waits for a rescan unless a bound forces it to.
+TEST INFRASTRUCTURE: a discrete-event simulation of the protocol, checked against a plain sequential restatement of
+farthest_point_sampling_kernel (sampling_gpu.cu:101-222: arg-max of the running min-distances, ties to the smallest
+(bitrev_{log2 S}(k mod S), k)).  It exists to show that the decision rule is SOUND whatever the schedule of its agents is — a
+sequencer that only ever sees published top-K records of the regions and never waits for a rescan unless a bound forces it to:
+  * `greedy=True`: the lockstep schedule of the kernels (the sequencer decides until it is blocked, then every owner applies
+    the round's picks and republishes: records are fresh at the start of a round);
+  * `delay=D`: records reach the sequencer D decisions late (the asynchronous form built and dropped in round 4);
+  * default: a random interleaving of owner steps and sequencer steps.
 
 Agents
   owner(region): holds the exact min-distances of its points; consumes the published picks in order; a pick whose distance
     to the region's bounding box is >= the region's current maximum cannot change anything and is skipped; otherwise the
-    region is rescanned and its record (tag a = picks applied, top-2 candidates under the reference's order) republished.
-  sequencer: holds, per region, the last record it accepted plus the CURRENT values cv1 / cv2 of the two candidates
-    (updated with every pick it makes, by the same distance expression the scan uses).  Region state at decision r:
-      X = better of (cv1, k1), (cv2, k2);  exact iff X >= (v2, k2) in the order (every other point of the region was
-      ordered after (v2, k2) when the record was made and min-distances only decrease), else unknown with bound v2.
+    region is rescanned and its record (tag a = picks applied, top-K candidates under the reference's order) republished.
+  sequencer: holds, per region, the last record it accepted plus the CURRENT values of its candidates (updated with every
+    pick it makes, by the same distance expression the scan uses).  Region state at decision r:
+      X = best current candidate;  exact iff X >= the record's LAST candidate as it was, in the order (every other point of
+      the region was ordered after that candidate when the record was made and min-distances only decrease), else unknown
+      with that candidate's old value as bound.
     pick r = best exact X, provided every unknown region's bound is strictly below its value; else wait for records.
 """
 import numpy as np

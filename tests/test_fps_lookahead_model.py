@@ -1,4 +1,5 @@
-"""The look-ahead sampler's decision rule is sound under any schedule (model: tests/models/fps_lookahead.py)."""
+"""The multi-pick samplers' decision rule is sound under any schedule (model: tests/models/fps_lookahead.py; kernels:
+csrc/fps_coop.hip, csrc/fps_seq.hip)."""
 import numpy as np
 import pytest
 
@@ -44,3 +45,28 @@ def test_lookahead_model_two_point_regions_and_single_region():
     want = M.fps_sequential(xyz, 64)
     assert M.run(xyz, 64, np.array_split(np.arange(64), 32), seed=3) == want     # regions of exactly two points
     assert M.run(xyz, 64, [np.arange(64)], seed=4) == want
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+@pytest.mark.parametrize("case", ["uniform", "lattice", "duplicates"])
+def test_lockstep_and_delayed_schedules(case, depth):
+    """the kernels' own schedule (lockstep rounds: `greedy`) and the delayed-record schedule, at the candidate depths the
+    kernels use (4; 2 and 1 for the record), give plain FPS; a round of the lockstep schedule makes at least one pick"""
+    rng = np.random.default_rng(7)
+    n, m, nreg = 512, 128, 16
+    if case == "uniform":
+        xyz = rng.uniform(-10, 10, (n, 3))
+    elif case == "lattice":
+        xyz = rng.integers(0, 6, (n, 3)).astype(np.float64)
+    else:
+        base = rng.uniform(-10, 10, (n // 4, 3))
+        xyz = base[rng.integers(0, n // 4, n)]
+    xyz = xyz.astype(np.float32)
+    want = M.fps_sequential(xyz, m)
+    regs = _regions(n, nreg, rng, True, xyz)
+    st = {}
+    assert M.run(xyz, m, regs, greedy=True, depth=depth, stats=st) == want
+    assert st['blocks'] <= m - 1                       # every round decided something
+    if depth > 1 and case == "uniform":
+        assert st['blocks'] < (m - 1) // 2             # ... and on ordinary clouds several picks
+    assert M.run(xyz, m, regs, delay=3, depth=depth) == want
