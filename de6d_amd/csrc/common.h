@@ -53,6 +53,8 @@ static inline bool det6d_switch_set(const char *name) { return getenv(name) != n
 static inline int det6d_env_int(const char *name, int dflt) { return det6d_switch_int(name, dflt); }
 static inline bool det6d_env_set(const char *name) { return det6d_switch_set(name); }
 #define D6_DBG_IS(v) (dbg == (v))
+// DET6D_DBG_POISON_LDS=<pattern>: fill the LDS of every CU before a sampler kernel (fps_seq.hip; tests only)
+void det6d_dbg_poison_lds_hook(hipStream_t stream);
 #else
 static inline int det6d_env_int(const char *, int dflt) { return dflt; }
 static inline bool det6d_env_set(const char *) { return false; }

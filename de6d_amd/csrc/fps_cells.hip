@@ -315,6 +315,7 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   // on clouds made of duplicated points: LABNOTES.md, round 4)
   static const int seq = det6d_env_int("DET6D_FPS_SEQ", 0);
   if (seq) return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
+  det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
 #endif
   static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
   hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,

@@ -457,7 +457,10 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
       if (lane < CPP) {
         const int w = lane >> LOG2K, c = lane & (K - 1);
         const int o = w * kCandMax + c;
-        const unsigned kword = (unsigned)rec.k[o] | ((unsigned)rec.nc[w] << 16);
+        // (slots c >= nc of a record have never been written in this launch if the wave's list has always been shorter: what
+        // they hold is whatever the LDS held before the kernel started.  Readers ignore such a slot — once they know nc, so
+        // nothing of the slot's own content may reach the nc field.)
+        const unsigned kword = ((unsigned)rec.k[o] & 0xFFFFu) | ((unsigned)rec.nc[w] << 16);
         unsigned long long *d = mine + (size_t)lane * 5;
         const unsigned long long w0 = co_pack(__builtin_bit_cast(unsigned, rec.v[o]), round), w1 = co_pack(kword, round),
                                  w2 = co_pack(__builtin_bit_cast(unsigned, rec.x[o]), round),
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
       }
       // gather: global candidate 64 s + lane = candidate (64 s + lane) % CPP of part (64 s + lane) / CPP
       float cv[SETS], qx[SETS], qy[SETS], qz[SETS], bound_v[SETS];
-      int kidx[SETS];
+      unsigned ntk[SETS];
       bool is_last[SETS];
       bool dead = false;
       const unsigned long long *base = slots + (size_t)(round & 1) * PARTS * CPP * 5;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
         const int nc = (int)(((unsigned)w1 >> 16) & 7u);
         const int slot = lane & (K - 1);
         cv[s_] = slot < nc ? __builtin_bit_cast(float, (unsigned)w0) : -1.0f;
-        kidx[s_] = (int)((unsigned)w1 & 0xFFFFu);
+        ntk[s_] = ~sq_tie_key((int)((unsigned)w1 & 0xFFFFu), log2s);      // ~tie key: larger wins
         qx[s_] = __builtin_bit_cast(float, (unsigned)w2);
         qy[s_] = __builtin_bit_cast(float, (unsigned)w3);
         qz[s_] = __builtin_bit_cast(float, (unsigned)w4);
@@ -516,33 +519,35 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
         if (lane == 0) { atomicExch(err, 1); abort_flag = 1; }
         if (part == 0) for (int i = r + lane; i < m; i += 64) idxs[i] = idx_add;   // in-range picks: nothing downstream may fault
       } else {
-        // per-round constants of every candidate: ntk = ~tie key (larger wins), thr = the smallest value that makes its region
-        // exact when THIS candidate holds it (the bound itself for the record's last candidate, the next float above it for the
-        // others), ubkey = the key of the region's bound when it is unknown
-        unsigned ntk[SETS], ubkey[SETS];
-        float thr[SETS];
+        // Keys: an exact candidate of value v has the EVEN key 2 bits(v) + 2, a region whose maximum is unknown the ODD key
+        // 2 bits(bound) + 3 (so that an unknown region outranks an exact candidate of the same value; 0 = no candidate).  A
+        // region is exact while one of its candidates reaches the bound: the record's last candidate at the bound itself, the
+        // others strictly above it — in keys: candidate key >= ub2 with ub2 = the unknown key - 1 for the last candidate and
+        // the unknown key itself for the others (even against odd: >= is > there).  One per-round constant per candidate.
+        unsigned ub2[SETS];
         bool deadc[SETS];
 #pragma unroll
         for (int s_ = 0; s_ < SETS; ++s_) {
-          ntk[s_] = ~sq_tie_key(kidx[s_], log2s);
           deadc[s_] = cv[s_] < 0.f;
-          const float bv = bound_v[s_];
-          thr[s_] = is_last[s_] ? bv : __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bv) + (bv >= 0.f ? 1u : 0u));
-          ubkey[s_] = bv < 0.f ? 0u : ((__builtin_bit_cast(unsigned, bv) << 1) | 1u) + 2u;
+          const unsigned ubk = ((__builtin_bit_cast(unsigned, bound_v[s_]) << 1) | 1u) + 2u;
+          ub2[s_] = is_last[s_] ? ubk - 1u : ubk;
         }
         const int jmax = min(max_picks, m - r);
         for (; j < jmax; ++j) {
+          unsigned ekey[SETS];
           float pe[SETS], ge[SETS];
 #pragma unroll
-          for (int s_ = 0; s_ < SETS; ++s_) pe[s_] = cv[s_] >= thr[s_] ? 1.0f : 0.0f;
+          for (int s_ = 0; s_ < SETS; ++s_) {
+            ekey[s_] = deadc[s_] ? 0u : (__builtin_bit_cast(unsigned, cv[s_]) << 1) + 2u;
+            pe[s_] = ekey[s_] >= ub2[s_] ? 1.0f : 0.0f;
+          }
           sq_group_max_n<K, SETS>(pe, ge);
           // this lane's best (key, ~tie key) over its sets as one 64-bit number
           u64 lbest = 0ull;
           int lset = 0;
 #pragma unroll
           for (int s_ = 0; s_ < SETS; ++s_) {
-            const unsigned ekey = deadc[s_] ? 0u : (__builtin_bit_cast(unsigned, cv[s_]) << 1) + 2u;
-            const unsigned key = ge[s_] != 0.0f ? ekey : ubkey[s_];
+            const unsigned key = ge[s_] != 0.0f ? ekey[s_] : (ub2[s_] | 1u);
             const u64 comp = ((u64)key << 32) | ntk[s_];
             const bool better = comp > lbest;
             lset = better ? s_ : lset;
@@ -551,19 +556,18 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
           const unsigned lkey = (unsigned)(lbest >> 32);
           const unsigned best = sq_wave_max_u32(lkey);
           if (best & 1u) break;                              // an unknown region may hold the maximum: the round ends
-          int kk = kidx[0];
           float ex = qx[0], ey = qy[0], ez = qz[0];
 #pragma unroll
           for (int s_ = 1; s_ < SETS; ++s_) {
             const bool sel = lset == s_;
-            kk = sel ? kidx[s_] : kk; ex = sel ? qx[s_] : ex; ey = sel ? qy[s_] : ey; ez = sel ? qz[s_] : ez;
+            ex = sel ? qx[s_] : ex; ey = sel ? qy[s_] : ey; ez = sel ? qz[s_] : ez;
           }
           const u64 tie = __ballot(lkey == best);
           int wl = __builtin_ctzll(tie);
           if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~(unsigned)lbest);
           if (lane == wl) {
             pick_x[j] = ex; pick_y[j] = ey; pick_z[j] = ez;
-            if (part == 0) idxs[r + j] = kk + idx_add;
+            if (part == 0) idxs[r + j] = sq_tie_key_point(~(unsigned)lbest, log2s) + idx_add;
           }
           const float sx = d6_readlane_f(ex, wl), sy = d6_readlane_f(ey, wl), sz = d6_readlane_f(ez, wl);
           if constexpr (SETS % 2 == 0) {
@@ -661,6 +665,9 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
   static const int max_picks = det6d_env_int("DET6D_FPS_SEQ_PICKS", kCoopMaxPicks);
+#ifdef DET6D_EXPERIMENTS
+  det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
+#endif
   if (multi) {
     if (parts == 4)
       hipLaunchKernelGGL((fps_coop_multi_kernel<4, kMultiCands>), dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride,

@@ -24,6 +24,11 @@ __device__ __forceinline__ unsigned sq_bitrev_bits(unsigned v, int bits) {
 __device__ __forceinline__ unsigned sq_tie_key(int k, int log2s) {
   return (sq_bitrev_bits((unsigned)k & ((1u << log2s) - 1u), log2s) << (32 - log2s)) | ((unsigned)k >> log2s);
 }
+// the point a tie key belongs to
+__device__ __forceinline__ int sq_tie_key_point(unsigned key, int log2s) {
+  if (log2s == 0) return (int)key;
+  return (int)(((key & ((1u << (32 - log2s)) - 1u)) << log2s) | sq_bitrev_bits(key >> (32 - log2s), log2s));
+}
 // lane holding the smallest key among the lanes of `cand` (tie path only)
 __device__ __forceinline__ int sq_min_key_lane(u64 cand, unsigned key) {
   const int lane = threadIdx.x & 63;
@@ -38,12 +43,15 @@ __device__ __forceinline__ int sq_min_key_lane(u64 cand, unsigned key) {
   return __builtin_ctzll(__ballot(mine && k == m));
 }
 
-// slot ws (wave-uniform) of this lane's coordinate registers: scalar binary search down to the statically indexed slot
+// slot ws (wave-uniform) of this lane's coordinate registers: scalar binary search down to the statically indexed slot.
+// (The empty asm in the leaf keeps the 16 leaves apart: without it the compiler merges them into ONE load with a computed
+// index, which moves px / py from registers into scratch memory — every sweep of the kernel then re-reads them from there.)
 template <int LO, int HI, int N>
 __device__ __forceinline__ void sq_select(int ws, const float (&px)[N], const float (&py)[N], const float (&pz)[N],
                                           float &x, float &y, float &z) {
   if constexpr (HI - LO == 1) {
     x = px[LO]; y = py[LO]; z = pz[LO];
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
   } else {
     constexpr int MID = (LO + HI) / 2;
     if (ws < MID) sq_select<LO, MID>(ws, px, py, pz, x, y, z);

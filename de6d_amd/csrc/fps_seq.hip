@@ -22,6 +22,7 @@
 //   fps_cells.hip), apply the ones that may matter in ONE pass and rewrite their record.
 // Two barriers per round; between them only wave 0 works (the other 15 sleep at the barrier: no issue slots taken from
 // co-resident GEMM waves).
+#include <stdio.h>
 #include "fps_multi.h"
 
 namespace {
@@ -188,6 +189,44 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
 extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_seq_stats(unsigned long long *out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(d6_fps_seq_stats), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
+
+// Test hook (DET6D_DBG_POISON_LDS=<pattern>, experiments build): the sampler launchers call this right before their sampling
+// kernel.  It fills the LDS of every CU with the pattern (one 160 KB workgroup per CU, several waves of them), so that a
+// kernel that reads LDS it has not written itself reads the pattern instead of whatever the kernels before left there — in
+// a fresh process mostly zeros, which hides such a read (round 4: fps_coop.hip's record slots).
+namespace {
+__device__ unsigned d6_poison_sink;
+__global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned pattern, unsigned words) {
+  extern __shared__ unsigned lds[];
+  for (unsigned i = threadIdx.x; i < words; i += 1024) lds[i] = pattern;
+  __syncthreads();
+  if (lds[(threadIdx.x * 97u) % words] != pattern) d6_poison_sink = 1u;     // (keeps the stores)
+}
+}  // namespace
+void det6d_dbg_poison_lds_hook(hipStream_t stream) {
+  static const char *env = getenv("DET6D_DBG_POISON_LDS");
+  if (!env) return;
+  static const unsigned pattern = (unsigned)strtoul(env, nullptr, 0);
+  const unsigned bytes = 160u * 1024u;
+  DET6D_MAX_DYNAMIC_LDS(poison_lds_kernel, bytes);
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), bytes, stream, pattern, bytes / 4u);
+  const hipError_t rc = hipGetLastError();
+  if (rc != hipSuccess) fprintf(stderr, "det6d_dbg_poison_lds_hook: %s\n", hipGetErrorString(rc));
+}
+// what an LDS word a workgroup has not written holds, on the CU the probing workgroup lands on (tests of the hook itself)
+namespace {
+__global__ __launch_bounds__(1024) void probe_lds_kernel(unsigned *out) {
+  __shared__ unsigned probe[8192];
+  unsigned v = probe[threadIdx.x * 8];
+  asm volatile("" : "+v"(v));
+  out[blockIdx.x * 1024 + threadIdx.x] = v;
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int det6d_dbg_probe_lds(unsigned *out, int blocks, void *stream) {
+  det6d_dbg_poison_lds_hook((hipStream_t)stream);
+  hipLaunchKernelGGL(probe_lds_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, out);
+  return det6d_check_launch("det6d_dbg_probe_lds");
+}
 #endif
 
 // Called by fps_cells.hip's launcher after the Morton sort and the lane-group ordering (groups of 16 positions).
@@ -198,6 +237,9 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, l
   static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
   static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
   const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
+#ifdef DET6D_EXPERIMENTS
+  det6d_dbg_poison_lds_hook(stream);
+#endif
   if (cands == 2)
     hipLaunchKernelGGL(fps_seq_kernel<2>, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
   else

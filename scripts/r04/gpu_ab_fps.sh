@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r04
 show='import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
-        d=json.loads(l); print(sys.argv[1], d["value"], d["config"]["window_ms_min_median_max"], "cold", d["cold"]["scenes_per_s"], "lat", d.get("latency_ms_per_batch"), d["selfcheck"])'
+        d=json.loads(l); print(sys.argv[1], d["value"], d["config"]["window_ms_min_median_max"], "cold", d["cold"]["scenes_per_s"], "lat", d.get("latency"), "lat_b1", d.get("latency_b1", {}).get("ms_per_frame"), d["selfcheck"])'
 B="--no-legs --cpu-scenes 0 --no-roofline --steps 20 --warmup 5"
 for i in 1 2; do
 DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=1 python3 bench.py $B 2>/dev/null | python3 -c "$show" "uniform seq"

@@ -343,6 +343,12 @@ def test_pruned_fps_kernel_is_exact():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_seq.py")],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ALL EXACT" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # ... and with the LDS of every CU filled with 0x7F7F0000 (a huge float, an index with high bits set) right before the sampling kernel (experiments build: same kernel
+    # source plus the fill hook, DET6D_DBG_POISON_LDS): a sampler must not read LDS it has not written
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_seq.py")],
+                         capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, DET6D_EXPERIMENTS_LIB="1", DET6D_DBG_POISON_LDS="0x7F7F0000"))
+    assert out.returncode == 0 and "ALL EXACT" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_skip_sampler_on_adversarial_clouds():
@@ -426,6 +432,13 @@ def test_cooperative_sampler_for_large_scenes():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ALL True" in out.stdout and "fallback" not in out.stdout, out.stdout
     print(out.stdout)
+    # the LDS of every CU filled with 0x7F7F0000 (a huge float, an index with high bits set) right before the sampling kernel (experiments build: same kernel source plus
+    # the fill hook, DET6D_DBG_POISON_LDS).  Round 4: a record slot never written in a launch leaked into the published candidate count — invisible in a
+    # fresh process, where the LDS is zero, and wrong picks in a long-lived one.
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_coop.py")], capture_output=True,
+                         text=True, timeout=1500, env=dict(os.environ, DET6D_EXPERIMENTS_LIB="1", DET6D_DBG_POISON_LDS="0x7F7F0000"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALL True" in out.stdout, out.stdout
 
 
 def test_ball_query_grid_adversarial(ext, oracle_ops):
