@@ -206,6 +206,24 @@ struct SqRecords {
   int nc[kWaves];
 };
 
+// Exact duplicates inside a lane.  A lane's slots are in the reference's order, so a point P' with the coordinates of an
+// earlier slot P of the same lane has P's min-distance at all times and loses every tie against it: P' is never the arg-max
+// of anything.  Its min-distance starts at 0 instead of 1e10, which takes it out of the lane's best / second bookkeeping —
+// otherwise a duplicated point costs its region's record two candidates that the same pick kills (clouds padded by
+// repetition, data_processor.py:170-175: "every point twice" ran at one pick per round).  The value 0 is what P' holds in
+// truth once P or P' has been picked, and a bound too low for P' is harmless: whenever P' is above it, so is P.
+template <int SG>
+__device__ __forceinline__ void sq_hide_lane_duplicates(const float (&px)[SG], const float (&py)[SG], const float (&pz)[SG],
+                                                        float (&pt)[SG]) {
+#pragma unroll
+  for (int j = 1; j < SG; ++j) {
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < j; ++i) dup |= px[i] == px[j] && py[i] == py[j] && pz[i] == pz[j];
+    pt[j] = dup ? 0.f : pt[j];
+  }
+}
+
 // min-distances of this wave's points against one more pick; no arg-max bookkeeping (the sq_rescan that closes the batch
 // does it once for all the picks)
 template <int SG>

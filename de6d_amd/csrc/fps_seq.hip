@@ -82,6 +82,7 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
     loy = d6_wave_min(ay); hiy = d6_wave_max(by);
     loz = d6_wave_min(az); hiz = d6_wave_max(bz);
   }
+  sq_hide_lane_duplicates<SG>(px, py, pz, pt);
   float cmax = __builtin_inff();
   // pick 0 is point 0 (sampling_gpu.cu:131-133): the first round's only pick; every wave's box test passes against +inf
   if (h == 0) { pick_x[0] = xyz[0]; pick_y[0] = xyz[1]; pick_z[0] = xyz[2]; pick_n = 1; idxs[0] = idx_add; }

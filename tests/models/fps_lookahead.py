@@ -58,11 +58,21 @@ def fps_sequential(xyz, m):
 
 
 class Region:
-    def __init__(self, ids, xyz, log2s):
+    def __init__(self, ids, xyz, log2s, hide=None):
         self.ids = np.asarray(ids)
         self.p = xyz[self.ids]
         self.t = np.full(len(ids), 1e10, np.float32)
         self.keys = [tie_key(k, log2s) for k in self.ids]
+        # sq_hide_lane_duplicates (csrc/fps_multi.h): a point with the coordinates of a point of the same region that comes
+        # EARLIER in the order may start at min-distance 0 — it is never an arg-max.  `hide` = the random generator that picks
+        # which of those points are hidden (the kernels hide the duplicates that share a lane, a subset).
+        if hide is not None:
+            seen = {}
+            for i in sorted(range(len(self.ids)), key=lambda i: self.keys[i]):
+                c = tuple(self.p[i].tolist())
+                if c in seen and hide.random() < 0.7:
+                    self.t[i] = np.float32(0)
+                seen.setdefault(c, i)
         self.lo, self.hi = self.p.min(0), self.p.max(0)
         self.applied = 0          # picks s_0 .. s_{applied-1} are in t
         self.cmax = np.float32(np.inf)
@@ -76,7 +86,7 @@ class Region:
         return [(np.float32(self.t[i]), int(self.ids[i]), self.p[i].copy()) for i in order]
 
 
-def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2):
+def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2, hide_duplicates=False):
     """regions: list of index arrays partitioning range(n).  Returns the picks; raises on a protocol violation.
     greedy: the sequencer decides until it is blocked, then every owner catches up (counts how often a rescan is on the
     critical path: stats['blocks'])."""
@@ -86,7 +96,7 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
     log2s = opt_log2s(n)
     key = lambda k: tie_key(k, log2s)
     better = lambda a, b: a[0] > b[0] or (a[0] == b[0] and key(a[1]) <= key(b[1]))      # a >= b in the order
-    owners = [Region(ids, xyz, log2s) for ids in regions]
+    owners = [Region(ids, xyz, log2s, hide=np.random.default_rng(seed + 77) if hide_duplicates else None) for ids in regions]
     hist = [xyz[0].copy()]          # published picks (positions); hist[0] is point 0
     picks = [0]
     records = [None] * len(owners)  # published: (tag, [(v1,k1,p1), (v2,k2,p2)])

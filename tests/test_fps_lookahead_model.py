@@ -70,3 +70,29 @@ def test_lockstep_and_delayed_schedules(case, depth):
     if depth > 1 and case == "uniform":
         assert st['blocks'] < (m - 1) // 2             # ... and on ordinary clouds several picks
     assert M.run(xyz, m, regs, delay=3, depth=depth) == want
+
+
+@pytest.mark.parametrize("case", ["duplicates", "lattice", "all_equal", "every_point_twice"])
+def test_hidden_duplicates_change_nothing(case):
+    """sq_hide_lane_duplicates: points that repeat an order-earlier point of their region start at min-distance 0 (out of the
+    records); the picks stay plain FPS under the lockstep, the delayed and a random schedule — including m > the number of
+    distinct points, where the reference re-picks"""
+    rng = np.random.default_rng(11)
+    n, m, nreg = 512, 160, 16
+    if case == "duplicates":
+        base = rng.uniform(-10, 10, (n // 4, 3))
+        xyz = base[rng.integers(0, n // 4, n)]
+    elif case == "lattice":
+        xyz = rng.integers(0, 4, (n, 3)).astype(np.float64)          # 64 distinct points: m exceeds them
+    elif case == "all_equal":
+        xyz = np.ones((n, 3)) * 3.25
+    else:
+        half = rng.uniform(-10, 10, (n // 2, 3))
+        xyz = np.concatenate([half, half])
+    xyz = xyz.astype(np.float32)
+    want = M.fps_sequential(xyz, m)
+    for spatial in (True, False):
+        regs = _regions(n, nreg, rng, spatial, xyz)
+        assert M.run(xyz, m, regs, greedy=True, depth=4, hide_duplicates=True, stats={}) == want
+        assert M.run(xyz, m, regs, delay=2, depth=2, hide_duplicates=True, seed=3) == want
+        assert M.run(xyz, m, regs, seed=5, hide_duplicates=True) == want
