@@ -1,4 +1,5 @@
-// fps_cells.hip — exact, spatially pruned farthest point sampling (D-FPS) of 16384-point scenes for gfx950.
+// fps_cells.hip — the pre-pass of the 16384-point farthest point samplers (D-FPS) for gfx950, their launcher, and (experiments
+// build only) the one-pick wave-skip sampler that shipped in rounds 2-3.
 //
 // Same result, bit for bit, as farthest_point_sampling_kernel
 // (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222) including its tie order, but a pick no longer
@@ -6,12 +7,17 @@
 //
 // Observation.  All min-distances satisfy temp[k] <= M, where M is the current maximum of a region.  A point can only change
 // in this round if d(k, s) < temp[k] <= M.  Points are pre-sorted into a 4 x 4 k-d grid of equal counts (cell_sort_kernel),
-// one cell per wave; a wave whose bounding box is at least sqrt(M) away from the new sample s cannot change, and its cached
-// arg-max stays valid.  The box test is exact in floating point: subtraction, multiplication and fma are monotone, so
+// one cell per wave; a wave whose bounding box is at least sqrt(M) away from the new sample s cannot change, and what it
+// published stays valid.  The box test is exact in floating point: subtraction, multiplication and fma are monotone, so
 // lb = fma(gz,gz, fma(gx,gx, gy*gy))  with per-axis gaps g <= |x_k - s| is a true lower bound of the distance the kernel
 // would compute for every point of the cell.  A new sample reaches 1.3 of the 16 boxes on average.
 // Ties (exactly equal maxima: duplicated points) are resolved on a slow path with the reference's order:
 // minimise (bitrev(k mod S), k).
+//
+// The sampling kernel is fps_seq.hip's multi-pick form (several picks per barrier round from published top-4 lists).  The
+// wave-skip kernel below (one pick per round: rescan -> LDS slot -> barrier -> block arg-max) is compiled into the experiments
+// build only (DET6D_FPS_SEQ=0): same-library A/B in the pipeline, round 4: 12.40-12.43 k scenes/s against 12.86-12.95 k
+// (benchmark scenes), 5.63 against 5.73 k (ray-cast); one frame on an idle chip 4.7 against 3.7 ms.
 #include "common.h"
 #include <stdlib.h>
 
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(512) void skip_group_order_kernel(int n, int log2s,
   for (int i = 0; i < GS; ++i) p[i] = v[i];
 }
 
+#ifdef DET6D_EXPERIMENTS      // ---- the one-pick wave-skip sampler: experiments build only (DET6D_FPS_SEQ=0)
 template <int LO, int HI, int N>
 __device__ __forceinline__ void skip_pick(int ws, int wl, const float (&px)[N], const float (&py)[N],
                                           const float (&pz)[N], float &sx, float &sy, float &sz) {
@@ -288,6 +295,8 @@ __global__ __launch_bounds__(64 * NW) void fps_skip_kernel(int n, int m, int log
   if (D6_DBG_IS(7) && h == 0 && blockIdx.x < 64) d6_fps_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+#endif  // DET6D_EXPERIMENTS
+
 }  // namespace
 
 #ifdef DET6D_EXPERIMENTS
@@ -297,28 +306,27 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsign
 }
 #endif
 
-// fps_seq.hip (experiments build only): the multi-pick sampler
-int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, long long xyz_bstride, long long idx_bstride,
-                         int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream);
+// fps_seq.hip: the multi-pick sampler
+int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                         const float *xyz, const int *perm, int *idx, hipStream_t stream);
 
 // Called by fps.hip's launcher for D-FPS of 16384-point scenes with fresh min-distances.  `perm` is (B, n) int32 scratch.
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                            const float *xyz, int *perm, int *idx, hipStream_t stream) {
   if (n != 16384) return DET6D_EINVAL;
   dim3 grid(b);
-  static const int dbg = det6d_env_int("DET6D_FPS_DBG", 0);  // timing experiments only
   hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
   hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
 #ifdef DET6D_EXPERIMENTS
-  // experiments build only, DET6D_FPS_SEQ=1: the multi-pick sampler (fps_seq.hip: several picks per barrier round from
-  // published top-4 lists; exact; 0.73-0.78 us per pick stand-alone against 0.83-0.85, no gain in the pipeline, 2.7x slower
-  // on clouds made of duplicated points: LABNOTES.md, round 4)
-  static const int seq = det6d_env_int("DET6D_FPS_SEQ", 0);
-  if (seq) return det6d_fps_seq_launch(b, n, m, log2s, 1, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
-  det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
+  static const int seq = det6d_env_int("DET6D_FPS_SEQ", 1);
+  if (!seq) {
+    static const int dbg = det6d_env_int("DET6D_FPS_DBG", 0);  // timing experiments only
+    det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
+    static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
+    hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,
+                       idx_add, dbg, xyz, perm, idx);
+    return det6d_check_launch("det6d_fps (wave skip)");
+  }
 #endif
-  static const unsigned hog = det6d_sampler_lds_hog(fps_skip_kernel<16, 16, 1>, 16 * 20 * 2 + 2 * 64 * 16 * 16);
-  hipLaunchKernelGGL((fps_skip_kernel<16, 16, 1>), grid, dim3(1024), hog, stream, n, m, log2s, xyz_bstride, idx_bstride,
-                     idx_add, dbg, xyz, perm, idx);
-  return det6d_check_launch("det6d_fps (wave skip)");
+  return det6d_fps_seq_launch(b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
 }

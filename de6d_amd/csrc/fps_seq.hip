@@ -2,7 +2,8 @@
 // farthest_point_sampling_kernel (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222, tie order of its
 // shared-memory tree :94-99,159-216), several picks per barrier round.
 //
-// The wave-skip sampler (fps_cells.hip) pays  rescan -> LDS slot -> s_barrier -> block arg-max  for EVERY pick: 0.86 us x 4095.
+// The 16384-point sampler of the library (pre-pass and launcher: fps_cells.hip).  The one-pick wave-skip sampler of rounds 2-3
+// (fps_cells.hip, experiments build) pays  rescan -> LDS slot -> s_barrier -> block arg-max  for EVERY pick: 0.84 us x 4095.
 // Here a round still has that shape, but the waves publish their top kCand points instead of their maximum, and one wave
 // (the sequencer, wave 0) decides AS MANY picks as those lists allow before the next round of rescans:
 //
@@ -231,10 +232,9 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_probe_lds(unsign
 #endif
 
 // Called by fps_cells.hip's launcher after the Morton sort and the lane-group ordering (groups of 16 positions).
-int det6d_fps_seq_launch(int b, int n, int m, int log2s, int regions_per_wave, long long xyz_bstride, long long idx_bstride,
-                         int idx_add, const float *xyz, const int *perm, int *idx, hipStream_t stream) {
+int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                         const float *xyz, const int *perm, int *idx, hipStream_t stream) {
   if (n != 16384) return DET6D_EINVAL;
-  (void)regions_per_wave;
   static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
   static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
   const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;

@@ -10,7 +10,7 @@ for roofline.traffic (HBM bytes per GEMM-family launch).
 import csv, glob, json, sys, collections
 root, steps = sys.argv[1], int(sys.argv[2])
 scenes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-FAMILIES = ('linear_kernel', 'mlp_chain', 'mlp_group', 'mlp_rows', 'group_expand', 'compact_groups', 'fps_coop', 'fps_skip_kernel', 'fps_fat_kernel', 'ball_query_pair_kernel', 'bq_grid', 'post_',
+FAMILIES = ('linear_kernel', 'mlp_chain', 'mlp_group', 'mlp_rows', 'group_expand', 'compact_groups', 'fps_coop', 'fps_skip_kernel', 'fps_seq_kernel', 'fps_fat_kernel', 'ball_query_pair_kernel', 'bq_grid', 'post_',
             'gather_rows', 'pack_points')
 out = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)

@@ -1,6 +1,6 @@
 """16384-point D-FPS against the oracle + timing, on uniform / ray-cast / duplicated / lattice / all-equal / outlier clouds.
-DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=1 selects the multi-pick sampler of the experiments build (csrc/fps_seq.hip); the
-shipped library always runs the wave-skip sampler.  python tests/gpu_scripts/fps_seq.py [quick]"""
+The library runs the multi-pick sampler (csrc/fps_seq.hip); DET6D_EXPERIMENTS_LIB=1 DET6D_FPS_SEQ=0 selects the one-pick
+wave-skip sampler of rounds 2-3 (csrc/fps_cells.hip, experiments build only).  python tests/gpu_scripts/fps_seq.py [quick]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -328,8 +328,9 @@ def test_fused_sampler_and_helpers(ext, oracle_ops):
 
 
 def test_pruned_fps_kernel_is_exact():
-    """fps_cells.hip: the wave-skip sampler (16384 points: 16 waves x 16 slots on k-d regions) gives the oracle's picks bit
-    for bit, duplicates and all-equal clouds included; the other sizes of the script run the fat-thread kernels"""
+    """fps_seq.hip on fps_cells.hip's k-d regions: the multi-pick sampler (16384 points: 16 waves x 16 slots, several picks
+    per barrier round) gives the oracle's picks bit for bit, duplicates and all-equal clouds included; the other sizes of the
+    first script run the fat-thread kernels.  The one-pick wave-skip sampler of rounds 2-3 (experiments build) likewise."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -349,10 +350,14 @@ def test_pruned_fps_kernel_is_exact():
                          capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, DET6D_EXPERIMENTS_LIB="1", DET6D_DBG_POISON_LDS="0x7F7F0000"))
     assert out.returncode == 0 and "ALL EXACT" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scripts", "fps_seq.py")],
+                         capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, DET6D_EXPERIMENTS_LIB="1", DET6D_FPS_SEQ="0", DET6D_DBG_POISON_LDS="0x7F7F0000"))
+    assert out.returncode == 0 and "ALL EXACT" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_skip_sampler_on_adversarial_clouds():
-    """wave-skip sampler: more seeds, a lattice with thousands of exact distance ties, collinear points, far
+    """16384-point sampler (fps_seq.hip): more seeds, a lattice with thousands of exact distance ties, collinear points, far
     outliers — always the oracle's indices"""
     import subprocess
     import sys
