@@ -1,6 +1,8 @@
 """Builds de6d_amd/csrc/libdet6d_hip.so (gfx950 only) with hipcc.  Works without a GPU
 (hipcc cross-compiles); the built library is git-ignored but travels with gpurun snapshots."""
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -54,10 +56,20 @@ def build(force=False, verbose=False, experiments=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            # the compiler's per-kernel resource report goes to <object>.usage.json (tests/test_build_resources.py: the
+            # latency-chain kernels must not touch scratch memory — round 4 lost 20 % of a sampler to an array the compiler
+            # had quietly moved there)
+            cmd = [hipcc] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            usage, rest = _parse_usage(proc.stderr)
+            if rest.strip():
+                sys.stderr.write(rest)
+            if proc.returncode != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+            with open(o + ".usage.json", "w") as f:
+                json.dump(usage, f)
         return o
 
     with ThreadPoolExecutor(max_workers=min(6, len(sources))) as ex:
@@ -67,7 +79,46 @@ def build(force=False, verbose=False, experiments=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    merged = {}
+    for o in objs:
+        if os.path.exists(o + ".usage.json"):
+            with open(o + ".usage.json") as f:
+                merged[os.path.basename(o).replace(".o", ".hip")] = json.load(f)
+    with open(lib.replace(".so", ".usage.json"), "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
     return lib
+
+
+_REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
+                     r"SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]|Dynamic Stack):\s+(\S+)")
+
+
+def _parse_usage(stderr):
+    """(-Rpass-analysis=kernel-resource-usage) -> {mangled kernel name: {field: value}}, and the rest of stderr"""
+    usage, rest, cur = {}, [], None
+    lines = stderr.splitlines(True)
+    skip = 0
+    for i, line in enumerate(lines):
+        if skip:
+            skip -= 1
+            continue
+        m = _REMARK.search(line)
+        if m:
+            key, val = m.group(1), m.group(2)
+            if key == "Function Name":
+                cur = usage.setdefault(val, {})
+                # clang echoes the source line and a caret under the first remark of a kernel
+                j = i + 1
+                while j < len(lines) and j <= i + 2 and (lines[j].lstrip().startswith("|") or re.match(r"\s*\d+ \|", lines[j])):
+                    j += 1
+                skip = j - i - 1
+            elif cur is not None:
+                cur[key.split(" [")[0]] = int(val) if val.lstrip("-").isdigit() else val
+            continue
+        if "[-Rpass-analysis=kernel-resource-usage]" in line:
+            continue
+        rest.append(line)
+    return usage, "".join(rest)
 
 
 if __name__ == "__main__":

@@ -520,35 +520,30 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
         if (lane == 0) { atomicExch(err, 1); abort_flag = 1; }
         if (part == 0) for (int i = r + lane; i < m; i += 64) idxs[i] = idx_add;   // in-range picks: nothing downstream may fault
       } else {
-        // Keys: an exact candidate of value v has the EVEN key 2 bits(v) + 2, a region whose maximum is unknown the ODD key
-        // 2 bits(bound) + 3 (so that an unknown region outranks an exact candidate of the same value; 0 = no candidate).  A
-        // region is exact while one of its candidates reaches the bound: the record's last candidate at the bound itself, the
-        // others strictly above it — in keys: candidate key >= ub2 with ub2 = the unknown key - 1 for the last candidate and
-        // the unknown key itself for the others (even against odd: >= is > there).  One per-round constant per candidate.
-        unsigned ub2[SETS];
-        bool deadc[SETS];
+        // Keys and the per-candidate constants thr / alt: fps_seq.hip (an exact candidate's even key 2 bits(v) + 2 against a
+        // region's odd unknown key 2 bits(bound) + 3; thr = the smallest key that makes the region exact through THIS
+        // candidate, alt = what the lane puts forward otherwise: the unknown key from the last candidate's lane, nothing from
+        // the others; an empty slot is never exact).  No reduction over a region's lanes is needed.
+        // (alt = thr + 1 in the last candidate's lane: recomputed per pick from a value the compiler cannot see through — a
+        // second array of per-round constants does not fit the 128 registers of a 1024-thread workgroup)
+        unsigned thr[SETS];
 #pragma unroll
         for (int s_ = 0; s_ < SETS; ++s_) {
-          deadc[s_] = cv[s_] < 0.f;
           const unsigned ubk = ((__builtin_bit_cast(unsigned, bound_v[s_]) << 1) | 1u) + 2u;
-          ub2[s_] = is_last[s_] ? ubk - 1u : ubk;
+          const unsigned ntk_last = sq_group_max_u32<K>(is_last[s_] ? ntk[s_] : 0u);
+          thr[s_] = cv[s_] < 0.f ? 0xFFFFFFFFu : ntk[s_] >= ntk_last ? ubk - 1u : ubk;
         }
         const int jmax = min(max_picks, m - r);
         for (; j < jmax; ++j) {
-          unsigned ekey[SETS];
-          float pe[SETS], ge[SETS];
-#pragma unroll
-          for (int s_ = 0; s_ < SETS; ++s_) {
-            ekey[s_] = deadc[s_] ? 0u : (__builtin_bit_cast(unsigned, cv[s_]) << 1) + 2u;
-            pe[s_] = ekey[s_] >= ub2[s_] ? 1.0f : 0.0f;
-          }
-          sq_group_max_n<K, SETS>(pe, ge);
           // this lane's best (key, ~tie key) over its sets as one 64-bit number
           u64 lbest = 0ull;
           int lset = 0;
 #pragma unroll
           for (int s_ = 0; s_ < SETS; ++s_) {
-            const unsigned key = ge[s_] != 0.0f ? ekey[s_] : (ub2[s_] | 1u);
+            const unsigned ekey = (__builtin_bit_cast(unsigned, cv[s_]) << 1) + 2u;
+            unsigned t = thr[s_];
+            asm volatile("" : "+v"(t));
+            const unsigned key = ekey >= t ? ekey : (is_last[s_] ? t + 1u : 0u);
             const u64 comp = ((u64)key << 32) | ntk[s_];
             const bool better = comp > lbest;
             lset = better ? s_ : lset;

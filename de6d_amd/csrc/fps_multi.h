@@ -148,6 +148,25 @@ __device__ __forceinline__ float sq_group_max(float a) {
   else return sq_quad_max(a);
 }
 
+// max over the lanes of a group (pair or quad) of an unsigned value, in all its lanes
+template <int K>
+__device__ __forceinline__ unsigned sq_group_max_u32(unsigned a) {
+  unsigned r;
+  if constexpr (K == 2)
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 : "=&v"(r) : "v"(a));
+  else
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 : "=&v"(r) : "v"(a));
+  return r;
+}
+
 // max over the 64 lanes of an unsigned value (uniform result)
 __device__ __forceinline__ unsigned sq_wave_max_u32(unsigned v) {
   unsigned t;

@@ -141,25 +141,37 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
       const int kidx = rec.k[o];
       const bool is_last = live && slot == nc - 1;
       const float bound_v = sq_group_max<kCand>(is_last ? cv : -2.0f);   // value of the record's last candidate (group-uniform)
+      // Keys: an exact candidate of value v has the EVEN key 2 bits(v) + 2 (values are >= +0: their bits order like the
+      // values and fit 31 bits), a region whose maximum is unknown the ODD key ub = 2 bits(bound) + 3, so that an unknown
+      // region outranks an exact candidate of the same value (it may hold a point of that value with a better tie key);
+      // 0 = nothing.  A region's maximum is exactly its best candidate X iff X is ordered before-or-at the record's last
+      // candidate L as it was — (value, tie key) of X now against (value, tie key) of L then: a value above the bound, or
+      // the bound itself with a tie key not after L's (L untouched is the plain case; a candidate that reaches the bound
+      // by coincidence with a later key is NOT such an X).  Every lane can tell that of its own candidate:
+      //   thr = the smallest key with which THIS candidate is such an X: ub - 1 (the bound itself) if its tie key is not
+      //         after L's, else ub (above the bound: even against odd, >= is >); all ones for an empty slot;
+      //   alt = what the lane puts forward otherwise: the region's unknown key from L's lane, nothing from the others.
+      // One wave-wide max then answers both questions: an X above the bound beats its own region's unknown key, and an
+      // untouched L withholds it.  (A touched L still puts the unknown key forward when another candidate sits exactly on
+      // the bound: conservative, the round ends early.  At the start of a round every L is untouched: no unknown key, the
+      // first decision always goes through.)
+      const unsigned ub = ((__builtin_bit_cast(unsigned, bound_v) << 1) | 1u) + 2u;
+      const bool alive = live && slot < nc;
+      const unsigned ntk = ~sq_tie_key(kidx, log2s);                                  // larger = earlier in the order
+      const unsigned ntk_last = sq_group_max_u32<kCand>(is_last ? ntk : 0u);
+      const unsigned thr = !alive ? 0xFFFFFFFFu : ntk >= ntk_last ? ub - 1u : ub;
+      const unsigned alt = is_last ? ub : 0u;
       int j = 0;
       const int jmax = min(max_picks, m - r);
       for (; j < jmax; ++j) {
-        // The region's maximum is exactly its best candidate X iff X is ordered before-or-at the record's last candidate as
-        // it was: some candidate's value above the bound, or the last candidate itself untouched (then X is that candidate
-        // or one ordered before it; an equal value reached by coincidence counts as unknown: the round ends, the region is
-        // rescanned — the pick that lowered its last candidate passes its box test — and is fresh in the next one).
-        const float pe = (cv > bound_v || (is_last && cv == bound_v)) ? 1.0f : 0.0f;
-        const bool exact = sq_group_max<kCand>(pe) != 0.0f;
-        // ONE reduction decides both questions: key = 2 * bits(value) + (1 for the bound of an unknown region, 0 for a
-        // candidate of an exact one); values are >= +0, so their bits order like the values and fit 31 bits; an empty slot
-        // (-1) has key 0, below the key 2 of a zero value.  The largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends.
-        const float val = exact ? cv : bound_v;
-        const unsigned key = val < 0.f ? 0u : ((__builtin_bit_cast(unsigned, val) << 1) | (exact ? 0u : 1u)) + 2u;
+        const unsigned ekey = (__builtin_bit_cast(unsigned, cv) << 1) + 2u;
+        const unsigned key = ekey >= thr ? ekey : alt;
+        // the largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends
         const unsigned best = sq_wave_max_u32(key);
         if (best & 1u) { SQ_STAT(4, 1); break; }
         const u64 tie = __ballot(key == best);
         int wl = __builtin_ctzll(tie);
-        if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, sq_tie_key(kidx, log2s));
+        if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~ntk);
         if (lane == wl) {                                  // the holder publishes the pick
           pick_x[j] = qx; pick_y[j] = qy; pick_z[j] = qz;
           idxs[r + j] = kidx + idx_add;

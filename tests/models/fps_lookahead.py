@@ -86,7 +86,7 @@ class Region:
         return [(np.float32(self.t[i]), int(self.ids[i]), self.p[i].copy()) for i in order]
 
 
-def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2, hide_duplicates=False):
+def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2, hide_duplicates=False, kernel_keys=False):
     """regions: list of index arrays partitioning range(n).  Returns the picks; raises on a protocol violation.
     greedy: the sequencer decides until it is blocked, then every owner catches up (counts how often a rescan is on the
     critical path: stats['blocks'])."""
@@ -129,7 +129,38 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
                         cv[j] = min(cv[j], sqdist(r[1][j][2][None], hist[i])[0])
                 st['cv'] = cv
 
+    def bits(v):
+        return int(np.float32(v).view(np.uint32))
+
+    def decide_with_kernel_keys():
+        """the key scheme of fps_seq.hip / fps_coop.hip: per candidate thr / alt, ONE global max, no per-region reduction"""
+        entries = []          # (key, tie key or None, candidate)
+        for st in seq:
+            if st['rec'] is None:
+                return False
+            v_l, k_l = st['rec'][-1][0], st['rec'][-1][1]
+            ub = 2 * bits(v_l) + 3
+            for j, (cv, c) in enumerate(zip(st['cv'], st['rec'])):
+                ekey = 2 * bits(cv) + 2
+                thr = ub - 1 if key(c[1]) <= key(k_l) else ub
+                if ekey >= thr:
+                    entries.append((ekey, key(c[1]), (cv, c[1], c[2])))
+                elif j == len(st['rec']) - 1:
+                    entries.append((ub, None, None))
+        top = max(e[0] for e in entries)
+        if top & 1:
+            return False
+        best = min((e for e in entries if e[0] == top), key=lambda e: e[1])[2]
+        picks.append(best[1])
+        hist.append(best[2].copy())
+        for st in seq:
+            for j in range(len(st['cv'])):
+                st['cv'][j] = min(st['cv'][j], sqdist(st['rec'][j][2][None], best[2])[0])
+        return True
+
     def sequencer_decide():
+        if kernel_keys:
+            return decide_with_kernel_keys()
         best, ub = None, np.float32(-np.inf)
         for st in seq:
             if st['rec'] is None:

@@ -96,3 +96,34 @@ def test_hidden_duplicates_change_nothing(case):
         assert M.run(xyz, m, regs, greedy=True, depth=4, hide_duplicates=True, stats={}) == want
         assert M.run(xyz, m, regs, delay=2, depth=2, hide_duplicates=True, seed=3) == want
         assert M.run(xyz, m, regs, seed=5, hide_duplicates=True) == want
+
+
+@pytest.mark.parametrize("case", ["uniform", "duplicates", "lattice", "all_equal", "every_point_twice"])
+@pytest.mark.parametrize("depth", [2, 4])
+def test_kernel_key_scheme(case, depth):
+    """the kernels' way of taking the decision — per candidate a threshold key and a fallback key, ONE maximum over all
+    candidates, no reduction per region (fps_seq.hip) — under the kernels' lockstep schedule and the delayed one, ties and
+    hidden duplicates included; a lockstep round always makes a pick"""
+    rng = np.random.default_rng(23)
+    n, m, nreg = 512, 200, 16
+    if case == "uniform":
+        xyz = rng.uniform(-10, 10, (n, 3))
+    elif case == "duplicates":
+        base = rng.uniform(-10, 10, (n // 4, 3))
+        xyz = base[rng.integers(0, n // 4, n)]
+    elif case == "lattice":
+        xyz = rng.integers(0, 4, (n, 3)).astype(np.float64)
+    elif case == "all_equal":
+        xyz = np.ones((n, 3)) * 3.25
+    else:
+        half = rng.uniform(-10, 10, (n // 2, 3))
+        xyz = np.concatenate([half, half])
+    xyz = xyz.astype(np.float32)
+    want = M.fps_sequential(xyz, m)
+    for spatial in (True, False):
+        regs = _regions(n, nreg, rng, spatial, xyz)
+        for hide in (False, True):
+            st = {}
+            assert M.run(xyz, m, regs, greedy=True, depth=depth, kernel_keys=True, hide_duplicates=hide, stats=st) == want
+            assert st['blocks'] <= m - 1
+            assert M.run(xyz, m, regs, delay=2, depth=depth, kernel_keys=True, hide_duplicates=hide, seed=9) == want
