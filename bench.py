@@ -102,7 +102,7 @@ def child_rate(args, env_extra, extra_args=(), note="", roofline=False):
     env.pop('WORLD_SIZE', None)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
            '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--worker', '--batch', str(args.batch), '--points', str(args.points), '--cfg', args.cfg,
-           '--streams', str(args.streams), '--group', str(args.group), '--prefetch', str(args.prefetch), '--merge', str(args.merge),
+           '--streams', str(args.raw_streams), '--group', str(args.group), '--prefetch', str(args.raw_prefetch), '--merge', str(args.merge),
            '--sampler-streams', str(args.sampler_streams), '--scene', args.scene] + (['--leg-roofline'] if roofline else []) + list(extra_args)
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -218,8 +218,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
     ap.add_argument('--merge', type=int, default=-1, help='consecutive batches coalesced into one pass (ScenePipeline merge); default: as many as make a pass of 32 scenes; 1 = one pass per batch')
-    ap.add_argument('--streams', type=int, default=-1, help='default 16; main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
-    ap.add_argument('--prefetch', type=int, default=4, help='groups whose sampler stage is issued ahead of the GEMM stage')
+    ap.add_argument('--streams', type=int, default=-1, help='default 16 (4 for 65536-point scenes: the same throughput at a third of the latency under load); main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
+    ap.add_argument('--prefetch', type=int, default=-1, help='groups whose sampler stage is issued ahead of the GEMM stage (default 4; 2 for scenes of more than 16384 points)')
     ap.add_argument('--sampler-streams', type=int, default=6)
     ap.add_argument('--group', type=int, default=-1, help='default 4 (merge 1) / 1 (coalesced passes); passes whose first (input-only) sampler runs as one launch; 0 = every pass is a single captured graph')
     ap.add_argument('--cfg', default='kitti_models/det6d_car.yaml')
@@ -243,8 +243,14 @@ def main():
         args.merge = 1 if (args.no_graph or args.group == 0) else coalesce_factor(args.batch, args.steps)
     if args.group < 0:
         args.group = 4 if args.merge == 1 else 1
+    # Pipeline depth by scene size: a pass of 65536-point scenes keeps the GEMM family busy 11x longer than one of 16384-point
+    # scenes, so 4 passes in flight saturate the chip (1244 scenes/s, p50 under load 154 ms; with 16: 1232 scenes/s, 517 ms:
+    # scripts/r04/gpu_tune_65536.sh).  The legs started by child_rate() resolve their own defaults from THEIR --points.
+    args.raw_streams, args.raw_prefetch = args.streams, args.prefetch
     if args.streams < 0:
-        args.streams = 16
+        args.streams = 16 if args.points <= 16384 else max(4, 16 * 16384 // args.points)
+    if args.prefetch < 0:
+        args.prefetch = 4 if args.points <= 16384 else 2
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # (torch.cuda.device_count() does not initialise the GPU)
