@@ -494,26 +494,34 @@ def main():
         if latency_under_load is not None:
             line["latency_under_load"] = latency_under_load
         if world == 1:
+            # Both runners are built BEFORE either is timed and freed after both: releasing a captured graph (its memory pool,
+            # its queues) right before a measurement inflates it (scripts/r04/latency_b1_ctx.py: 3.35 -> 3.7 ms after `del`
+            # of one runner, 13 ms for the first frame after a pipeline was freed).  Medians over the timed launches.
             lat = GraphedDet6D(model, b, n, points=points)
-            lat.launch(); lat.finalize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                lat.launch(); lat.finalize()
-            line["latency"] = {"ms_per_batch": round((time.perf_counter() - t0) / 5 * 1e3, 3),
-                               "note": "one batch of %d scenes, one captured graph on one stream, idle chip" % b}
-            del lat
             # one frame, idle chip: the shape of the reference's single-frame callers (sim/gazebo/src/detection/script/
             # detection.py:108-126,185-188; core/tools/demo.py)
             one = torch.from_numpy(synth_points(4242, 1, n, tilt=args.tilt, scene=args.scene)).cuda()
             lat1 = GraphedDet6D(model, 1, n, points=one)
-            lat1.launch(); lat1.finalize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                lat1.launch(); lat1.finalize()
-            line["latency_b1"] = {"ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 3),
+            torch.cuda.synchronize()
+
+            def _median_ms(runner, reps):
+                for _ in range(2):
+                    runner.launch(); runner.finalize()
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    runner.launch(); runner.finalize()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                return round(ts[len(ts) // 2], 3), round(ts[0], 3), round(ts[-1], 3)
+            med, lo, hi = _median_ms(lat, 7)
+            line["latency"] = {"ms_per_batch": med, "ms_min_max": [lo, hi],
+                               "note": "one batch of %d scenes, one captured graph on one stream, idle chip; median of 7" % b}
+            med, lo, hi = _median_ms(lat1, 11)
+            line["latency_b1"] = {"ms_per_frame": med, "ms_min_max": [lo, hi],
                                   "note": "ONE scene of %d points, one captured graph on one stream, idle chip, host launch -> "
-                                          "detections on the host" % n}
-            del lat1, one
+                                          "detections on the host; median of 11" % n}
+            del lat, lat1, one
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS)
             line["roofline"]["scenes_per_pass"] = b * merge

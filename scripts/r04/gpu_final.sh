@@ -7,7 +7,7 @@ grep '^{' gpurun_out/r04_final/bench_20.log | cut -c1-200; tail -4 gpurun_out/r0
 bash scripts/r04/gpu_pmc_all.sh z
 for sc in uniform beam; do
   out=gpurun_out/r04_pipe_$sc; mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipe -- python3 bench.py --steps 192 --warmup 48 --cpu-scenes 0 --no-roofline --no-legs --scene $sc > $out/bench_stdout.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipe -- python3 bench.py --steps 192 --warmup 48 --cpu-scenes 0 --no-roofline --no-legs --scene $sc > $out/bench_stdout.log 2>&1
   grep '^{' $out/bench_stdout.log > $out/bench_under_profiler.json; cut -c1-200 $out/bench_under_profiler.json
   f=$(find $out -name "*kernel_stats.csv" | head -1); cp $f $out/pipeline_kernel_stats.csv
   t=$(find $out -name "*kernel_trace.csv" | head -1)
@@ -15,7 +15,7 @@ for sc in uniform beam; do
   rm -f $t
 done
 out=gpurun_out/r04_pipe_65536; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipe -- python3 bench.py --steps 40 --warmup 8 --cpu-scenes 0 --no-roofline --no-legs --cfg synthetic_models/det6d_65536.yaml --points 65536 --batch 8 > $out/bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipe -- python3 bench.py --steps 40 --warmup 8 --cpu-scenes 0 --no-roofline --no-legs --cfg synthetic_models/det6d_65536.yaml --points 65536 --batch 8 > $out/bench_stdout.log 2>&1
 grep '^{' $out/bench_stdout.log > $out/bench_under_profiler.json; cut -c1-200 $out/bench_under_profiler.json
 f=$(find $out -name "*kernel_stats.csv" | head -1); cp $f $out/pipeline_kernel_stats.csv; head -8 $f | cut -c1-150
 find $out -name "*kernel_trace.csv" -delete

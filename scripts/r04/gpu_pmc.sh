@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=24
 tag=${1:-r04}; shift; out=gpurun_out/pmc_$tag; mkdir -p $out
 STEPS=${STEPS:-6}; WARM=2
 A="--steps $STEPS --warmup $WARM --batch ${BATCH:-32} --streams 1 --no-graph --cpu-scenes 0 --no-roofline --no-legs --preroll 0 --windows 1 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py $A > $out/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py $A > $out/stats.log 2>&1
 grep '^{' $out/stats.log | cut -c1-300
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; head -12 $f | cut -c1-160
 python3 - $out/stats $out <<'PY'
@@ -24,7 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
          "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES"; do
   t=$(echo $c | tr ' ' '_' | cut -c1-24)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$t -o pmc -- python3 bench.py $A > $out/$t.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$t -o pmc -- python3 bench.py $A > $out/$t.log 2>&1
   grep '^{' $out/$t.log | cut -c1-120
 done
 n=$(python3 - $out <<'PY'
