@@ -587,10 +587,10 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
     if (need > 0 && avail >= need)
       return det6d_fps_coop_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x, ws, out, (hipStream_t)stream);
   }
-  // 16384 points: the multi-pick sampler of fps_seq.hip on the k-d regions of fps_cells.hip (16 points per lane in registers,
-  // one bounding box per wave; the permutation lives in `temp`, which is free because the min-distances start at 1e10
-  // implicitly): same picks bit for bit, 0.57 vs 1.35 us per pick of the plain fat-thread kernel
-  if (temp && x && out && b > 0 && m > 0 && n == 16384)
+  // 16384 / 4096 points: the multi-pick sampler of fps_seq.hip on the k-d regions of fps_cells.hip (16 / 4 points per lane in
+  // registers, one bounding box per wave; the permutation lives in `temp`, which is free because the min-distances start at
+  // 1e10 implicitly): same picks bit for bit, 0.51 vs 1.35 us per pick of the plain fat-thread kernel at 16384 points
+  if (temp && x && out && b > 0 && m > 0 && (n == 16384 || n == 4096))
     return det6d_fps_cells_launch(b, n, m, opt_n_threads_log2(n), vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x,
                                   reinterpret_cast<int *>(temp), out, (hipStream_t)stream);
   return launch_fps<false>(b, n, m, x, nullptr, temp, out, vw, (hipStream_t)stream);

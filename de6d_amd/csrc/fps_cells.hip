@@ -310,11 +310,16 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_fps_clock(unsign
 int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                          const float *xyz, const int *perm, int *idx, hipStream_t stream);
 
-// Called by fps.hip's launcher for D-FPS of 16384-point scenes with fresh min-distances.  `perm` is (B, n) int32 scratch.
+// Called by fps.hip's launcher for D-FPS of 16384- and 4096-point scenes with fresh min-distances.  `perm` is (B, n) int32 scratch.
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                            const float *xyz, int *perm, int *idx, hipStream_t stream) {
-  if (n != 16384) return DET6D_EINVAL;
+  if (n != 16384 && n != 4096) return DET6D_EINVAL;
   dim3 grid(b);
+  if (n == 4096) {      // 1024 lanes x 4 points
+    hipLaunchKernelGGL((cell_sort_kernel<4>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
+    hipLaunchKernelGGL(skip_group_order_kernel<4>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+    return det6d_fps_seq_launch(b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
+  }
   hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
   hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
 #ifdef DET6D_EXPERIMENTS

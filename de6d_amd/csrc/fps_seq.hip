@@ -40,12 +40,12 @@ __device__ unsigned long long d6_fps_seq_stats[16];
 
 // One workgroup of 16 waves per scene.  `perm`: the scene's Morton permutation whose lane groups of 16 consecutive positions
 // are ordered by tie key (fps_cells.hip: cell_sort_kernel + skip_group_order_kernel<16>).
-template <int kCand>
+template <int kCand, int SG = kSlots>
 __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
                                                        int idx_add, const float *__restrict__ xyz,
                                                        const int *__restrict__ perm, int *__restrict__ idxs, int max_picks) {
-  constexpr int SG = kSlots;
-  __shared__ unsigned short korig[64 * kWaves * kSlots];   // sorted position -> original index
+  // SG points per lane: 16 for 16384-point scenes, 4 for 4096-point ones (n = 1024 SG)
+  __shared__ unsigned short korig[64 * kWaves * SG];       // sorted position -> original index
   __shared__ SqRecords rec;
   __shared__ float pick_x[kMaxPicks], pick_y[kMaxPicks], pick_z[kMaxPicks];
   __shared__ int pick_n;
@@ -246,16 +246,18 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_probe_lds(unsign
 // Called by fps_cells.hip's launcher after the Morton sort and the lane-group ordering (groups of 16 positions).
 int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                          const float *xyz, const int *perm, int *idx, hipStream_t stream) {
-  if (n != 16384) return DET6D_EINVAL;
+  if (n != 16384 && n != 4096) return DET6D_EINVAL;
   static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
   static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
   const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
 #ifdef DET6D_EXPERIMENTS
   det6d_dbg_poison_lds_hook(stream);
 #endif
-  if (cands == 2)
-    hipLaunchKernelGGL(fps_seq_kernel<2>, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+  if (n == 4096)
+    hipLaunchKernelGGL((fps_seq_kernel<4, 4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+  else if (cands == 2)
+    hipLaunchKernelGGL((fps_seq_kernel<2>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
   else
-    hipLaunchKernelGGL(fps_seq_kernel<4>, dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+    hipLaunchKernelGGL((fps_seq_kernel<4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
   return det6d_check_launch("det6d_fps (multi-pick)");
 }

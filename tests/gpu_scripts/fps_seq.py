@@ -53,5 +53,17 @@ if not quick:
     good &= bool(run('outliers', out, 1024))
     good &= bool(run('b=32', np.ascontiguousarray(make_batch(9, 32, n)[..., :3]), 4096, check=2, reps=3))
     good &= bool(run('m=n', u[:1], n, check=1, reps=1))
+# 4096-point scenes (the second layer's d-fps): the same kernel with 4 points per lane
+n4 = 4096
+u4 = np.ascontiguousarray(make_batch(21, 8, n4, dup_frac=0.05)[..., :3])
+good &= bool(run('4096: uniform dup 5%', u4, 512))
+d4 = u4.copy(); d4[:, n4 // 2:] = d4[:, :n4 - n4 // 2]
+if not quick:
+    good &= bool(run('4096: ray-cast', np.ascontiguousarray(beam_batch(5, 8, n4)[..., :3]), 512))
+    good &= bool(run('4096: every point twice', d4, 1024))
+    good &= bool(run('4096: lattice (exact ties)', np.random.default_rng(1).integers(0, 8, (2, n4, 3)).astype(np.float32), 700))
+    good &= bool(run('4096: all equal', np.ones((2, n4, 3), np.float32), 64))
+    good &= bool(run('4096: m=n', u4[:1], n4, check=1, reps=1))
+
 print('ALL EXACT' if good else 'MISMATCH')
 sys.exit(0 if good else 1)
