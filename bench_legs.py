@@ -257,7 +257,10 @@ def linear_roofline(model, points, batch, flops_per_scene, streams=None, pmc_tag
     def _kind(f):
         f = os.path.basename(f)
         return 'beam' if 'beam' in f else '65536' if '65536' in f else 'uniform'
-    pmc = sorted(f for f in __import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')) if _kind(f) == pmc_tag)
+    def _order(f):        # rNN_<tag> (a round's final collection) after rNNa_<tag> (its first), later rounds last
+        m_ = __import__('re').match(r'r(\d+)([a-z]?)_', os.path.basename(f))
+        return (int(m_.group(1)), m_.group(2) == '', f) if m_ else (-1, False, f)
+    pmc = sorted((f for f in __import__('glob').glob(os.path.join(ROOT, 'profiles', '*pmc_summary.json')) if _kind(f) == pmc_tag), key=_order)
     if os.environ.get('DET6D_DENSE_ROWS'):
         pmc = []
     if pmc:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
