@@ -2,12 +2,12 @@
 // farthest_point_sampling_kernel (core/pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-222, tie order of its
 // shared-memory tree :94-99,159-216), several picks per barrier round.
 //
-// The 16384-point sampler of the library (pre-pass and launcher: fps_cells.hip).  The one-pick wave-skip sampler of rounds 2-3
+// The 16384- and 4096-point D-FPS of the library (pre-pass and launcher: fps_cells.hip).  The one-pick wave-skip sampler of rounds 2-3
 // (fps_cells.hip, experiments build) pays  rescan -> LDS slot -> s_barrier -> block arg-max  for EVERY pick: 0.84 us x 4095.
 // Here a round still has that shape, but the waves publish their top kCand points instead of their maximum, and one wave
 // (the sequencer, wave 0) decides AS MANY picks as those lists allow before the next round of rescans:
 //
-//   Record of a wave (region = the 1024 Morton-consecutive points it holds in registers), rewritten whenever a pick may
+//   Record of a wave (region = the k-d cell of 1024 / 256 points it holds in registers), rewritten whenever a pick may
 //   have changed the region: its top (up to) kCand points c_1 > c_2 > .. in the reference's order (value descending, then
 //   tie key ascending) as {value, index, x, y, z}.  Every other point of the region is ordered AFTER the last candidate,
 //   and min-distances only decrease.
@@ -16,7 +16,7 @@
 //   exactly X  iff  X is ordered before-or-at the record's last candidate as it was; otherwise the maximum is unknown but
 //   <= that candidate's old value.  The next pick is the best exact X provided every unknown region's bound is strictly
 //   below it; otherwise the round ends.  At the start of a round every record is fresh, so the first pick always goes
-//   through: a round makes >= 1 pick, typically 4-6 (tests/models/fps_lookahead.py, `greedy` schedule, is this rule as an
+//   through: a round makes >= 1 pick, 8.5 on average (tests/models/fps_lookahead.py, `greedy` schedule, is this rule as an
 //   executable model; tests/test_fps_lookahead_model.py checks it against plain FPS on ties, duplicates, lattices).
 //   Owners (all 16 waves): test the round's picks against their bounding box (a pick at least sqrt(current maximum) away
 //   changes nothing: the floating-point box distance is a lower bound of every distance the scan would compute,
