@@ -53,7 +53,7 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
 // Any permutation is CORRECT for the samplers below; the order only makes their regions compact.
 // ------------------------------------------------------------------------------------------------
 template <int IPT>
-__global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bstride, const float *__restrict__ xyz,
+__global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long long xyz_bstride, const float *__restrict__ xyz,
                                                          int *__restrict__ perm) {
   typedef hipcub::BlockRadixSort<unsigned, 1024, IPT, int> Sort;
   __shared__ typename Sort::TempStorage sort_tmp;
@@ -83,65 +83,63 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, long long xyz_bs
   // positions [g n/16, (g+1) n/16).  A wave of the samplers below owns one region (n = 16384), and its bounding box is a
   // tight rectangle: a new sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into
   // 16 equal runs gives 2.65: a run that crosses a quadrant boundary of the curve has a box that spans both quadrants.
-  const float sx = xmax > xmin ? 1048575.0f / (xmax - xmin) : 0.f;
-  const float sy = ymax > ymin ? 1048575.0f / (ymax - ymin) : 0.f;
+  // The first sort only decides which strip a point belongs to (10-bit keys: 3 radix passes), the second the cell inside the
+  // strip and the order inside the cell (2 + 14 bits: 4 passes; exact duplicates share a key and stay neighbours, which is what
+  // lets sq_hide_lane_duplicates find them in one lane).  20-bit keys in both (11 passes) bought nothing measurable.
+  const float sx = xmax > xmin ? 1023.0f / (xmax - xmin) : 0.f;
+  const float sy = ymax > ymin ? 16383.0f / (ymax - ymin) : 0.f;
   unsigned key[IPT];
   int val[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     float fx = (x[i] - xmin) * sx;
-    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1048575.f) : 0.f;
+    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1023.f) : 0.f;
     key[i] = (unsigned)fx;
     val[i] = tid * IPT + i;
   }
   __syncthreads();
-  Sort(sort_tmp).Sort(key, val, 0, 20);
+  Sort(sort_tmp).Sort(key, val, 0, 10);
   // sorted position p = tid * IPT + i now holds point val[i]; its strip is p / (n / 4)
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     const float yy = xyz[(size_t)val[i] * 3 + 1];
     float fy = (yy - ymin) * sy;
-    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 1048575.f) : 0.f;
-    key[i] = ((unsigned)((tid * IPT + i) / (n / 4)) << 20) | (unsigned)fy;
+    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 16383.f) : 0.f;
+    key[i] = ((unsigned)((tid * IPT + i) / (n / 4)) << 14) | (unsigned)fy;
   }
   __syncthreads();
-  Sort(sort_tmp).Sort(key, val, 0, 22);
+  Sort(sort_tmp).Sort(key, val, 0, 16);
+  // The IPT consecutive positions of this thread are exactly the slots of ONE lane of the samplers: order them by the
+  // reference's tie key here (the strict '>' of a lane's scan then keeps the right point among equal values), in registers.
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) key[i] = tie_key(val[i], log2s);
+#pragma unroll
+  for (int i = 1; i < IPT; ++i) {
+#pragma unroll
+    for (int j = i; j > 0; --j) {
+      const bool sw = key[j - 1] > key[j];
+      const unsigned ka = sw ? key[j] : key[j - 1], kb = sw ? key[j - 1] : key[j];
+      const int va = sw ? val[j] : val[j - 1], vb = sw ? val[j - 1] : val[j];
+      key[j - 1] = ka; key[j] = kb; val[j - 1] = va; val[j] = vb;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < IPT; ++i) perm[tid * IPT + i] = val[i];
 }
 
+#ifdef DET6D_EXPERIMENTS      // ---- the one-pick wave-skip sampler: experiments build only (DET6D_FPS_SEQ=0)
 // ------------------------------------------------------------------------------------------------
-// Wave-skip sampler: the fat-thread kernel of fps.hip on Morton-sorted points, with ONE bounding box per
+// Wave-skip sampler: the fat-thread kernel of fps.hip on the k-d sorted points, with ONE bounding box per
 // wave.  A wave whose box is at least sqrt(its current maximum) away from the new sample cannot change
 // and keeps its cached arg-max; only the waves near the sample rescan their 32 points per lane.  Same
 // register footprint and round latency as the fat kernel, but ~1/5 of its vector-ALU instructions once
 // the first few hundred samples are placed — and on gfx950 every VALU instruction of a co-resident kernel
 // is time taken from the fp32 MFMAs of the GEMM waves on that SIMD.
 // Exactness: (1) the box test is a floating-point lower bound of the distance the scan would compute
-// (monotone ops, see the top of this file); (2) ties: the pre-pass orders the 32 points of a lane by the
+// (monotone ops, see the top of this file); (2) ties: the pre-pass orders the points of a lane by the
 // reference's tie key, so the strict `>` of the scan keeps the right one inside a lane; ties between
 // lanes / waves take the explicit min-key slow path.
 // ------------------------------------------------------------------------------------------------
-template <int GS>
-__global__ __launch_bounds__(512) void skip_group_order_kernel(int n, int log2s, int *__restrict__ perm) {
-  // one thread per group of GS consecutive sorted positions (= one lane's slots): insertion sort by tie key
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  int *p = perm + (size_t)blockIdx.y * n + (size_t)g * GS;
-  if (g * GS >= n) return;
-  int v[GS];
-  unsigned key[GS];
-  for (int i = 0; i < GS; ++i) { v[i] = p[i]; key[i] = tie_key(v[i], log2s); }
-  for (int i = 1; i < GS; ++i) {
-    const int vi = v[i];
-    const unsigned ki = key[i];
-    int j = i;
-    while (j > 0 && key[j - 1] > ki) { v[j] = v[j - 1]; key[j] = key[j - 1]; --j; }
-    v[j] = vi; key[j] = ki;
-  }
-  for (int i = 0; i < GS; ++i) p[i] = v[i];
-}
-
-#ifdef DET6D_EXPERIMENTS      // ---- the one-pick wave-skip sampler: experiments build only (DET6D_FPS_SEQ=0)
 template <int LO, int HI, int N>
 __device__ __forceinline__ void skip_pick(int ws, int wl, const float (&px)[N], const float (&py)[N],
                                           const float (&pz)[N], float &sx, float &sy, float &sz) {
@@ -316,12 +314,10 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
   if (n != 16384 && n != 4096) return DET6D_EINVAL;
   dim3 grid(b);
   if (n == 4096) {      // 1024 lanes x 4 points
-    hipLaunchKernelGGL((cell_sort_kernel<4>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-    hipLaunchKernelGGL(skip_group_order_kernel<4>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+    hipLaunchKernelGGL((cell_sort_kernel<4>), grid, dim3(1024), 0, stream, n, log2s, xyz_bstride, xyz, perm);
     return det6d_fps_seq_launch(b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
   }
-  hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, xyz_bstride, xyz, perm);
-  hipLaunchKernelGGL(skip_group_order_kernel<16>, dim3(2, b), dim3(512), 0, stream, n, log2s, perm);
+  hipLaunchKernelGGL((cell_sort_kernel<16>), grid, dim3(1024), 0, stream, n, log2s, xyz_bstride, xyz, perm);
 #ifdef DET6D_EXPERIMENTS
   static const int seq = det6d_env_int("DET6D_FPS_SEQ", 1);
   if (!seq) {

@@ -38,8 +38,8 @@ __device__ unsigned long long d6_fps_seq_stats[16];
 #define SQ_STAT(i, v) do { } while (0)
 #endif
 
-// One workgroup of 16 waves per scene.  `perm`: the scene's Morton permutation whose lane groups of 16 consecutive positions
-// are ordered by tie key (fps_cells.hip: cell_sort_kernel + skip_group_order_kernel<16>).
+// One workgroup of 16 waves per scene.  `perm`: the scene's k-d permutation whose lane groups of SG consecutive positions
+// are ordered by tie key (fps_cells.hip: cell_sort_kernel).
 template <int kCand, int SG = kSlots>
 __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
                                                        int idx_add, const float *__restrict__ xyz,
