@@ -13,7 +13,7 @@ typedef float sq_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCandMax = 4;              // candidates per record = sequencer lanes per region (2 or 4)
 constexpr int kWaves = 16, kSlots = 16;  // 16 x 64 x 16 = 16384 points
-constexpr int kMaxPicks = 16;            // picks per round at most (one workgroup per scene)
+constexpr int kMaxPicks = 32;            // picks per round at most (one workgroup per scene)
 constexpr int kCoopMaxPicks = 64;        // ... of the cooperative form (one per lane of the owners' box test)
 static_assert(kWaves * kCandMax == 64, "one sequencer lane per candidate");
 
