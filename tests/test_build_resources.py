@@ -44,3 +44,24 @@ def test_samplers_fit_a_full_workgroup(usage):
     for name, u in usage.items():
         if "fps_seq_kernel" in name or "fps_coop_multi_kernel" in name:
             assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["Occupancy"] >= 4, (name, u)
+
+
+def test_resource_report_parser():
+    """de6d_amd/_build.py: the remarks of -Rpass-analysis=kernel-resource-usage -> per-kernel fields; everything else passes through"""
+    from de6d_amd._build import _parse_usage
+    text = (
+        "/x/a.hip:10:1: remark: Function Name: _Z3foov [-Rpass-analysis=kernel-resource-usage]\n"
+        "   10 | __global__ void foo() {\n"
+        "      | ^\n"
+        "/x/a.hip:10:1: remark:     TotalSGPRs: 20 [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:10:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:10:1: remark:     ScratchSize [bytes/lane]: 144 [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:10:1: remark:     Dynamic Stack: False [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:10:1: remark:     LDS Size [bytes/block]: 34888 [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:22:3: warning: something else\n"
+        "/x/a.hip:30:1: remark: Function Name: _Z3barv [-Rpass-analysis=kernel-resource-usage]\n"
+        "/x/a.hip:30:1: remark:     VGPRs Spill: 3 [-Rpass-analysis=kernel-resource-usage]\n")
+    usage, rest = _parse_usage(text)
+    assert usage == {"_Z3foov": {"TotalSGPRs": 20, "VGPRs": 128, "ScratchSize": 144, "Dynamic Stack": "False", "LDS Size": 34888},
+                     "_Z3barv": {"VGPRs Spill": 3}}
+    assert rest == "/x/a.hip:22:3: warning: something else\n"
