@@ -271,7 +271,7 @@ __device__ __forceinline__ void sq_apply(float cx, float cy, float cz, const flo
 template <int SG, int kCand>
 __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log2s, const float (&px)[SG], const float (&py)[SG],
                                            const float (&pz)[SG], float (&pt)[SG], const unsigned short *korig_w, SqRecords &rec,
-                                           int wave) {
+                                           int wave, int depth = kCand) {
   const int lane = threadIdx.x & 63;
   float best = -1.0f, sec = -1.0f;
   int bs = 0;
@@ -313,8 +313,10 @@ __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log
   float head = best;
   float cmax = 0.f;
   int nc = 0;
+  // `depth` (1 .. kCand, wave-uniform): how many candidates to list.  A shorter list is as valid as a long one — only less
+  // useful to the sequencer — and an extraction step costs ~600 cycles: the callers ask for few while rounds make few picks.
 #pragma nounroll
-  for (int i = 0; i < kCand; ++i) {
+  for (int i = 0; i < depth; ++i) {
     const float wm = d6_wave_max(head);
     if (i == 0) cmax = wm;
     const u64 tie = __ballot(head == wm);

@@ -43,7 +43,7 @@ __device__ unsigned long long d6_fps_seq_stats[16];
 template <int kCand, int SG = kSlots>
 __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
                                                        int idx_add, const float *__restrict__ xyz,
-                                                       const int *__restrict__ perm, int *__restrict__ idxs, int max_picks) {
+                                                       const int *__restrict__ perm, int *__restrict__ idxs, int max_picks, int depth_add) {
   // SG points per lane: 16 for 16384-point scenes, 4 for 4096-point ones (n = 1024 SG)
   __shared__ unsigned short korig[64 * kWaves * SG];       // sorted position -> original index
   __shared__ SqRecords rec;
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
         }
         const int i = __builtin_ctzll(need);
         SQ_STAT(2, 1);
-        cmax = sq_rescan<SG, kCand>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave);
+        // list depth: one more candidate than the last round made picks (early rounds — every pick reaches every region — make
+        // one or two: top-4 lists would be extracted for nothing)
+        cmax = sq_rescan<SG, kCand>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave,
+                                    min(kCand, max(1, np + depth_add)));
       }
     }
     if (r >= m) break;                                    // (uniform over the workgroup: r is advanced by pick_n everywhere)
@@ -249,15 +252,16 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, 
   if (n != 16384 && n != 4096) return DET6D_EINVAL;
   static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
   static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
+  static const int depth_add = det6d_env_int("DET6D_FPS_SEQ_DEPTH_ADD", 1);
   const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
 #ifdef DET6D_EXPERIMENTS
   det6d_dbg_poison_lds_hook(stream);
 #endif
   if (n == 4096)
-    hipLaunchKernelGGL((fps_seq_kernel<4, 4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+    hipLaunchKernelGGL((fps_seq_kernel<4, 4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks, depth_add);
   else if (cands == 2)
-    hipLaunchKernelGGL((fps_seq_kernel<2>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+    hipLaunchKernelGGL((fps_seq_kernel<2>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks, depth_add);
   else
-    hipLaunchKernelGGL((fps_seq_kernel<4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks);
+    hipLaunchKernelGGL((fps_seq_kernel<4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks, depth_add);
   return det6d_check_launch("det6d_fps (multi-pick)");
 }
