@@ -448,7 +448,7 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
         }
         const int i = __builtin_ctzll(need);
         cmax = sq_rescan<SG, K>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave,
-                                min(K, np + 1));       // (list depth: fps_seq.hip)
+                                np <= 1 ? min(K, 2) : K);       // (list depth: fps_seq.hip)
       }
     }
     if (r >= m || abort_flag) break;

@@ -113,10 +113,12 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
         }
         const int i = __builtin_ctzll(need);
         SQ_STAT(2, 1);
-        // list depth: one more candidate than the last round made picks (early rounds — every pick reaches every region — make
-        // one or two: top-4 lists would be extracted for nothing)
+        // list depth: short lists after a round that made a single pick (the first rounds — every pick reaches every region —
+        // make one each: top-4 lists would be extracted for nothing), full lists otherwise.  (Tying the depth to the number
+        // of picks more closely — picks + 1 — is a trap: short lists make short rounds make short lists; ray-cast scenes stayed
+        // there for long stretches, 2.03 -> 2.69 ms.)
         cmax = sq_rescan<SG, kCand>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pt, korig_w, rec, wave,
-                                    min(kCand, max(1, np + depth_add)));
+                                    np <= depth_add ? min(kCand, 2) : kCand);
       }
     }
     if (r >= m) break;                                    // (uniform over the workgroup: r is advanced by pick_n everywhere)
@@ -252,7 +254,7 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, 
   if (n != 16384 && n != 4096) return DET6D_EINVAL;
   static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
   static const int cands = det6d_env_int("DET6D_FPS_SEQ_CANDS", 4);
-  static const int depth_add = det6d_env_int("DET6D_FPS_SEQ_DEPTH_ADD", 1);
+  static const int depth_add = det6d_env_int("DET6D_FPS_SEQ_DEPTH_ADD", 1);    // rounds of <= this many picks are followed by short lists
   const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
 #ifdef DET6D_EXPERIMENTS
   det6d_dbg_poison_lds_hook(stream);
