@@ -65,5 +65,9 @@ if not quick:
     good &= bool(run('4096: all equal', np.ones((2, n4, 3), np.float32), 64))
     good &= bool(run('4096: m=n', u4[:1], n4, check=1, reps=1))
 
+if not quick:        # tiny pick counts: the first rounds on their own (short lists, one pick per round)
+    for mm in (1, 2, 3, 33):
+        good &= bool(run('m=%d' % mm, u[:3], mm, check=3, reps=1))
+        good &= bool(run('4096: m=%d' % mm, u4[:3], mm, check=3, reps=1))
 print('ALL EXACT' if good else 'MISMATCH')
 sys.exit(0 if good else 1)
