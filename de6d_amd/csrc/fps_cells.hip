@@ -55,8 +55,20 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
 template <int IPT>
 __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long long xyz_bstride, const float *__restrict__ xyz,
                                                          int *__restrict__ perm) {
-  typedef hipcub::BlockRadixSort<unsigned, 1024, IPT, int> Sort;
-  __shared__ typename Sort::TempStorage sort_tmp;
+  // A 4 x 4 k-d grid of equal counts: order by x, cut into 4 strips, order every strip by y, cut into 4: region g = sorted
+  // positions [g n/16, (g+1) n/16).  A wave of the samplers owns one region, and its bounding box is a tight rectangle: a new
+  // sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into 16 equal runs gives 2.65: a
+  // run that crosses a quadrant boundary of the curve has a box that spans both quadrants.
+  // Two COUNTING sorts in LDS (histogram -> exclusive scan -> one atomic per point for its position): 1024 x bins decide the
+  // strip, n / 4 y bins per strip the position inside it.  The order inside a bin is whatever the atomics make it — any
+  // permutation is correct, and exact duplicates (same bin) stay within a bin's few points of each other, which is what lets
+  // sq_hide_lane_duplicates find most of them in one lane.  (Rounds 2-4 ran two block radix sorts here: 124 us for 16384 points.)
+  constexpr int N = 1024 * IPT;
+  constexpr int BY = N / 4;                    // y bins per strip: one point per bin on average
+  typedef hipcub::BlockScan<unsigned, 1024> Scan;
+  __shared__ typename Scan::TempStorage scan_tmp;
+  __shared__ unsigned bins[N];                 // histogram, then running offsets (x pass: the first 1024)
+  __shared__ int sorted[N];
   __shared__ float red[4][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   xyz += (size_t)blockIdx.x * xyz_bstride;
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
-    const int k = tid * IPT + i;
+    const int k = i * 1024 + tid;              // (coalesced: the point a thread holds does not matter here)
     x[i] = xyz[(size_t)k * 3 + 0];
     y[i] = xyz[(size_t)k * 3 + 1];
     if (x[i] == x[i] && fabsf(x[i]) < 1e30f) { xmin = fminf(xmin, x[i]); xmax = fmaxf(xmax, x[i]); }
@@ -73,46 +85,65 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   }
   xmin = d6_wave_min(xmin); xmax = d6_wave_max(xmax); ymin = d6_wave_min(ymin); ymax = d6_wave_max(ymax);
   if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = ymin; red[3][wave] = ymax; }
+  bins[tid] = 0u;
   __syncthreads();
   xmin = red[0][0]; xmax = red[1][0]; ymin = red[2][0]; ymax = red[3][0];
   for (int w = 1; w < 16; ++w) {
     xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
     ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
   }
-  // A 4 x 4 k-d grid of equal counts: sort by x, cut into 4 strips, sort every strip by y, cut into 4: region g = sorted
-  // positions [g n/16, (g+1) n/16).  A wave of the samplers below owns one region (n = 16384), and its bounding box is a
-  // tight rectangle: a new sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into
-  // 16 equal runs gives 2.65: a run that crosses a quadrant boundary of the curve has a box that spans both quadrants.
-  // The first sort only decides which strip a point belongs to (10-bit keys: 3 radix passes), the second the cell inside the
-  // strip and the order inside the cell (2 + 14 bits: 4 passes; exact duplicates share a key and stay neighbours, which is what
-  // lets sq_hide_lane_duplicates find them in one lane).  20-bit keys in both (11 passes) bought nothing measurable.
   const float sx = xmax > xmin ? 1023.0f / (xmax - xmin) : 0.f;
-  const float sy = ymax > ymin ? 16383.0f / (ymax - ymin) : 0.f;
-  unsigned key[IPT];
-  int val[IPT];
+  const float sy = ymax > ymin ? (float)(BY - 1) / (ymax - ymin) : 0.f;
+  // ---- x: strip of every point
+  unsigned bin[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     float fx = (x[i] - xmin) * sx;
     fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1023.f) : 0.f;
-    key[i] = (unsigned)fx;
-    val[i] = tid * IPT + i;
+    bin[i] = (unsigned)fx;
+    atomicAdd(&bins[bin[i]], 1u);
   }
   __syncthreads();
-  Sort(sort_tmp).Sort(key, val, 0, 10);
-  // sorted position p = tid * IPT + i now holds point val[i]; its strip is p / (n / 4)
+  {
+    unsigned off;
+    Scan(scan_tmp).ExclusiveSum(bins[tid], off);
+    __syncthreads();
+    bins[tid] = off;
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
-    const float yy = xyz[(size_t)val[i] * 3 + 1];
-    float fy = (yy - ymin) * sy;
-    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 16383.f) : 0.f;
-    key[i] = ((unsigned)((tid * IPT + i) / (n / 4)) << 14) | (unsigned)fy;
+    const unsigned pos = atomicAdd(&bins[bin[i]], 1u);     // 0 .. N-1, each once: exactly N / 4 points per strip
+    float fy = (y[i] - ymin) * sy;
+    fy = fy == fy ? fminf(fmaxf(fy, 0.f), (float)(BY - 1)) : 0.f;
+    bin[i] = (pos / (unsigned)(N / 4)) * (unsigned)BY + (unsigned)fy;
   }
   __syncthreads();
-  Sort(sort_tmp).Sort(key, val, 0, 16);
+  // ---- y inside the strips: N bins (strip-major), thread t scans bins t IPT .. t IPT + IPT - 1
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) bins[i * 1024 + tid] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) atomicAdd(&bins[bin[i]], 1u);
+  __syncthreads();
+  {
+    unsigned cnt[IPT], total = 0u, base;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) { cnt[i] = bins[tid * IPT + i]; total += cnt[i]; }
+    Scan(scan_tmp).ExclusiveSum(total, base);
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) { bins[tid * IPT + i] = base; base += cnt[i]; }   // (every thread rewrites only its own bins)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) sorted[atomicAdd(&bins[bin[i]], 1u)] = i * 1024 + tid;
+  __syncthreads();
   // The IPT consecutive positions of this thread are exactly the slots of ONE lane of the samplers: order them by the
   // reference's tie key here (the strict '>' of a lane's scan then keeps the right point among equal values), in registers.
+  unsigned key[IPT];
+  int val[IPT];
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) key[i] = tie_key(val[i], log2s);
+  for (int i = 0; i < IPT; ++i) { val[i] = sorted[tid * IPT + i]; key[i] = tie_key(val[i], log2s); }
 #pragma unroll
   for (int i = 1; i < IPT; ++i) {
 #pragma unroll
