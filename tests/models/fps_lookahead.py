@@ -115,7 +115,8 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
             o.t = np.minimum(o.t, sqdist(o.p, s))
             o.applied += 1
             o.cmax = o.t.max()
-            records[w] = (o.applied, o.top2(depth))
+            # (depth 0: every record gets a list length of its own, 1 .. 4 — the kernels shorten their lists after single-pick rounds)
+            records[w] = (o.applied, o.top2(depth if depth > 0 else int(rng.integers(1, 5))))
 
     def sequencer_poll():
         for w, st in enumerate(seq):

@@ -127,3 +127,25 @@ def test_kernel_key_scheme(case, depth):
             assert M.run(xyz, m, regs, greedy=True, depth=depth, kernel_keys=True, hide_duplicates=hide, stats=st) == want
             assert st['blocks'] <= m - 1
             assert M.run(xyz, m, regs, delay=2, depth=depth, kernel_keys=True, hide_duplicates=hide, seed=9) == want
+
+
+@pytest.mark.parametrize("case", ["uniform", "lattice", "every_point_twice"])
+def test_lists_of_varying_length(case):
+    """records may list 1 .. 4 candidates, each record a length of its own (the kernels ask for short lists after single-pick
+    rounds): still plain FPS, with the kernels' key scheme and hidden duplicates"""
+    rng = np.random.default_rng(31)
+    n, m, nreg = 512, 180, 16
+    if case == "uniform":
+        xyz = rng.uniform(-10, 10, (n, 3))
+    elif case == "lattice":
+        xyz = rng.integers(0, 4, (n, 3)).astype(np.float64)
+    else:
+        half = rng.uniform(-10, 10, (n // 2, 3))
+        xyz = np.concatenate([half, half])
+    xyz = xyz.astype(np.float32)
+    want = M.fps_sequential(xyz, m)
+    regs = _regions(n, nreg, rng, True, xyz)
+    for seed in (1, 2):
+        assert M.run(xyz, m, regs, greedy=True, depth=0, kernel_keys=True, hide_duplicates=True, stats={}, seed=seed) == want
+        assert M.run(xyz, m, regs, delay=2, depth=0, kernel_keys=True, seed=seed) == want
+        assert M.run(xyz, m, regs, depth=0, seed=seed) == want
