@@ -9,6 +9,26 @@ Layout:
 """
 __version__ = "0.1.0"
 
+import os as _os
+import sys as _sys
+
+
+def _export_hw_queues():
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
+    initialises.  The throughput pipeline (runtime.ScenePipeline) keeps 16 + 6 streams busy; on 4 queues it runs 4x slower.
+    So: when this process has not initialised the GPU yet and the caller has not chosen a value, export 24 here; when it HAS
+    (the ROS-node shape: sim/gazebo/src/detection/script/detection.py:108-126 builds its CUDA context first), remember what
+    was in effect — runtime.require_hw_queues() raises instead of running aliased."""
+    torch = _sys.modules.get('torch')
+    if torch is not None and torch.cuda.is_initialized():
+        return int(_os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    _os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
+    return None
+
+
+#: hardware queues in effect if HIP was already initialised when the package was imported, else None (the variable is live)
+HW_QUEUES_AT_IMPORT = _export_hw_queues()
+
 
 #: where the reference imports its two compiled extension modules from
 #: (core/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py:7, core/pcdet/ops/iou3d_nms/iou3d_nms_utils.py:9)

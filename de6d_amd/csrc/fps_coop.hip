@@ -439,7 +439,8 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
       const float gy = fmaxf(0.f, fmaxf(loy - sy, sy - hiy));
       const float gz = fmaxf(0.f, fmaxf(loz - sz, sz - hiz));
       const float lb = d6_sqdist(gx, gy, gz);
-      u64 need = __ballot(lane < np && !(lb >= cmax));
+      // (the first round always rescans: see fps_seq.hip)
+      u64 need = __ballot(lane < np && (round == 1u || !(lb >= cmax)));
       if (need != 0ull) {
         while (need & (need - 1ull)) {
           const int i = __builtin_ctzll(need);
@@ -661,7 +662,8 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   const int grid = 8 * parts * ((b + 7) / 8);
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
-  static const int max_picks = det6d_env_int("DET6D_FPS_SEQ_PICKS", kCoopMaxPicks);
+  // (clamped like fps_seq.hip's: 0 would never advance a round, more than kCoopMaxPicks would write past the pick arrays in LDS)
+  static const int max_picks = std::min(std::max(det6d_env_int("DET6D_FPS_SEQ_PICKS", kCoopMaxPicks), 1), (int)kCoopMaxPicks);
 #ifdef DET6D_EXPERIMENTS
   det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
 #endif

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
       const float gz = fmaxf(0.f, fmaxf(loz - sz, sz - hiz));
       const float lb = d6_sqdist(gx, gy, gz);
       // (tested against the maximum BEFORE the batch: min-distances only decrease, the test stays conservative)
-      u64 need = __ballot(lane < np && !(lb >= cmax));
+      // (the first round always rescans: a wave's record is written by its first rescan, and a point 0 with a huge or
+      // infinite coordinate would make lb overflow to +inf == cmax)
+      u64 need = __ballot(lane < np && (r == 1 || !(lb >= cmax)));
       if (need != 0ull) {
         while (need & (need - 1ull)) {
           const int i = __builtin_ctzll(need);

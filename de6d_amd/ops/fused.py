@@ -55,9 +55,12 @@ def fps_fused(xyz, lo, hi, m, scores, gamma, idx_out, idx_offset, temp=None, idx
             if ctl is not None and hasattr(ctl, 'status_words'):
                 ctl.status_words.append(word)
             elif not torch.cuda.is_current_stream_capturing():
-                if len(PENDING_FPS_STATUS) >= 64:          # nobody drained the list: look at the words before any is dropped
-                    check_fps_status()
+                # this launch's word first, then the drain: a drain that raises must not lose the word of the launch that
+                # triggered it.  (Nobody drained the list for 64 launches: the check below SYNCHRONISES the current stream —
+                # this launch included — and raises FpsTimeout here, for whichever of the 65 launches gave up.)
                 PENDING_FPS_STATUS.append(word)
+                if len(PENDING_FPS_STATUS) > 64:
+                    check_fps_status()
 
 
 #: error words (int32 device views) of eager cooperative sampler launches that nobody has checked yet

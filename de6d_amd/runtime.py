@@ -521,8 +521,13 @@ class Det6DGroup(object):
         """did a hoisted sampler give up in (or before, and unreported until) launch `gen`?  Every pass of that launch gets
         the same answer.  The device words are sticky: they are cleared here, once per failed launch, on the sampler stream
         (ordered against the next stage-1 launch), so launches issued before the clear report the failure too."""
-        if gen < 0 or gen <= self._gen - self._status_ring:
+        if gen < 0:
             return False
+        if gen <= self._gen - self._status_ring:
+            # the pinned row of that launch has been reused by a later one: whether its samplers gave up is no longer known
+            raise RuntimeError("Det6DGroup: launch %d was finalized %d launches late (status ring of %d): finalize every pass of "
+                               "a group launch before the group has been launched %d more times"
+                               % (gen, self._gen - gen, self._status_ring, self._status_ring))
         if not bool(self._status_host[gen % self._status_ring].any()):
             return False
         if gen > self._cleared_gen:
@@ -550,15 +555,24 @@ class Det6DGroup(object):
 COOP_CU_FRACTION = 1.0
 
 
-def warn_hw_queues(need):
-    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the
-    runtime initialises: with fewer queues than streams the passes in flight serialise"""
-    have = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
-    if have < need:
-        import warnings
-        warnings.warn("GPU_MAX_HW_QUEUES=%d but the pipeline uses %d HIP streams: they will alias onto the hardware "
-                      "queues and serialise; export GPU_MAX_HW_QUEUES=24 before the process touches the GPU" % (have, need),
-                      RuntimeWarning, stacklevel=3)
+def hip_initialised():
+    """has this process initialised the HIP runtime through torch?  (GPU_MAX_HW_QUEUES is read at that moment)"""
+    return bool(torch.cuda.is_initialized())
+
+
+def require_hw_queues(need, allow_aliasing=False):
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable ONCE, when the runtime
+    initialises: with fewer queues than streams the passes in flight alias onto the queues and serialise (2 051 instead of
+    9 680 scenes/s, bench.py:56-61) — silently.  `import de6d_amd` exports 24 when nothing has touched the GPU yet
+    (de6d_amd/__init__.py); a process that initialised HIP first with fewer queues than `need` gets a RuntimeError here instead
+    of a 4x slower pipeline, unless it asks for the aliased form (`allow_aliasing=True`: results are identical, only slower)."""
+    from . import HW_QUEUES_AT_IMPORT
+    have = HW_QUEUES_AT_IMPORT if HW_QUEUES_AT_IMPORT is not None else int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    if have < need and not allow_aliasing:
+        raise RuntimeError("the pipeline uses %d HIP streams but this process has GPU_MAX_HW_QUEUES=%d hardware queues (the variable "
+                           "is read when the HIP runtime initialises): export GPU_MAX_HW_QUEUES=24 — or import de6d_amd — before "
+                           "the process touches the GPU, or pass allow_aliasing=True to run on aliased, serialising queues"
+                           % (need, have))
     return have
 
 
@@ -587,13 +601,14 @@ class ScenePipeline(object):
         return [torch.cat([batches[(i * merge + j) % len(batches)] for j in range(merge)], 0) for i in range(n_pass)]
 
     def __init__(self, model, batch_size, n_points, n_main=16, group=4, prefetch=4, sampler_streams=6, points=None,
-                 point_width=5, main_streams=None, samplers=None, merge=1):
+                 point_width=5, main_streams=None, samplers=None, merge=1, allow_aliasing=False):
         self.merge = max(1, int(merge))
         self.step_scenes = batch_size
         batch_size = batch_size * self.merge
         self.k = max(1, min(group, n_main))
         self.prefetch = prefetch
-        warn_hw_queues(n_main + sampler_streams)
+        self.hw_queues = require_hw_queues((len(main_streams) if main_streams else n_main) +
+                                           (len(samplers) if samplers else sampler_streams), allow_aliasing)
         self.main_streams = list(main_streams) if main_streams else [torch.cuda.Stream() for _ in range(n_main)]
         self.sampler_streams = list(samplers) if samplers else [torch.cuda.Stream() for _ in range(sampler_streams)]
         from .ops import fused

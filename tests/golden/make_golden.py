@@ -65,6 +65,36 @@ def gen_nms():
         out["iou_%d" % k] = iou
         for thr in (0.01, 0.1, 0.7):
             out["keep_%d_%s" % (k, str(thr).replace('.', 'p'))] = oops.nms_from_iou(iou, thr)
+    # Round-4 review: 7 sizes x 3 thresholds is a thin pin for a mask kernel.  24 more sets of random size K in [1, 1024]
+    # (block-boundary sizes included) in which a third of the boxes are NEAR-THRESHOLD partners of earlier boxes: the same
+    # footprint shifted along its heading by d = l (1 - t) / (1 + t) (IoU == t for equal boxes), t one of the three test
+    # thresholds, pushed off the threshold by a relative 1e-4 .. 1e-2 either way, some with a small extra yaw.  Only boxes
+    # and keep lists are stored (an IoU matrix of K = 1024 is 4 MB); `rmargin_*` records how close to the threshold the
+    # reference's own IoUs come (the parity tests' IoU tolerance is 2e-5).
+    rng = np.random.default_rng(20261003)
+    sizes = [1, 2, 3, 64, 65, 127, 128, 129, 1023, 1024] + [int(v) for v in rng.integers(1, 1025, 14)]
+    out["random_sizes"] = np.array(sizes, np.int64)
+    for c, k in enumerate(sizes):
+        boxes = random_boxes(7000 + c, k, spread=float(rng.uniform(6.0, 60.0)))
+        for j in range(1, k):
+            if rng.uniform() < 0.34:
+                i = int(rng.integers(0, j))
+                t = (0.01, 0.1, 0.7)[int(rng.integers(0, 3))]
+                eps = float(10.0 ** rng.uniform(-4.0, -2.0)) * (1.0 if rng.uniform() < 0.5 else -1.0)
+                length = float(boxes[i, 3])
+                d = length * (1.0 - t * (1.0 + eps)) / (1.0 + t * (1.0 + eps))
+                boxes[j] = boxes[i]
+                boxes[j, 0] += np.float32(d * np.cos(boxes[i, 6]))
+                boxes[j, 1] += np.float32(d * np.sin(boxes[i, 6]))
+                if rng.uniform() < 0.25:
+                    boxes[j, 6] += np.float32(rng.uniform(-0.02, 0.02))
+        iou = oref.boxes_iou_bev_cpu(boxes, boxes)
+        out["rboxes_%d" % c] = boxes
+        off = iou[~np.eye(k, dtype=bool)] if k > 1 else np.zeros(1, np.float32)
+        for thr in (0.01, 0.1, 0.7):
+            tag = str(thr).replace('.', 'p')
+            out["rkeep_%d_%s" % (c, tag)] = oops.nms_from_iou(iou, thr)
+            out["rmargin_%d_%s" % (c, tag)] = np.float32(np.abs(off - np.float32(thr)).min())
     np.savez_compressed(os.path.join(HERE, "nms_ref.npz"), **out)
     print("nms_ref.npz", len(out), "arrays")
 

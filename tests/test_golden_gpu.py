@@ -23,6 +23,20 @@ def test_nms_keep_lists_of_reference_iou3d_cpu():
             np.testing.assert_array_equal(keep[:num].numpy(), z['keep_%d_%s' % (k, str(thr).replace('.', 'p'))])
 
 
+def test_nms_random_sets_with_near_threshold_pairs():
+    """nms_gpu (mask kernel + greedy scan) and the fused post-processing's NMS on 24 random sets, K in [1, 1024], with
+    near-threshold pairs, against the reference's iou3d_cpu.cpp keep lists"""
+    from de6d_amd.ops import iou3d_nms_hip as nm
+    z = np.load(os.path.join(G, 'nms_ref.npz'))
+    for c, k in enumerate(z['random_sizes']):
+        boxes = torch.from_numpy(z['rboxes_%d' % c]).cuda()
+        for thr in (0.01, 0.1, 0.7):
+            keep = torch.zeros(int(k), dtype=torch.int64)
+            num = nm.nms_gpu(boxes, keep, thr)
+            np.testing.assert_array_equal(keep[:num].numpy(), z['rkeep_%d_%s' % (c, str(thr).replace('.', 'p'))],
+                                          err_msg='set %d (K = %d) thr %s' % (c, k, thr))
+
+
 def test_box_decode_of_reference_coder():
     from de6d_amd.pcdet.utils.box_coder_utils import PointBinResidual6DCoder
     z = np.load(os.path.join(G, 'box_coder.npz'))

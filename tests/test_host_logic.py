@@ -256,3 +256,32 @@ def test_bench_refuses_more_ranks_than_devices():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert 'visible device' in (out.stderr + out.stdout)
+
+
+def test_hardware_queue_rule(monkeypatch):
+    """GPU_MAX_HW_QUEUES is read when HIP initialises: importing the package exports 24 while nothing has touched the GPU;
+    require_hw_queues raises (instead of the round-4 warning) when fewer queues than streams are in effect, unless the caller
+    asks for the aliased form"""
+    import subprocess
+    import sys
+    import de6d_amd
+    from de6d_amd import runtime
+    # a fresh interpreter that has not chosen a value gets 24 from the import, one that has keeps its own
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import de6d_amd; print(os.environ['GPU_MAX_HW_QUEUES'], de6d_amd.HW_QUEUES_AT_IMPORT)"
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ['24', 'None'], out.stdout + out.stderr
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '8'; import de6d_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ['8']
+    monkeypatch.setattr(de6d_amd, 'HW_QUEUES_AT_IMPORT', None)
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '24')
+    assert runtime.require_hw_queues(22) == 24
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    with pytest.raises(RuntimeError, match='GPU_MAX_HW_QUEUES'):
+        runtime.require_hw_queues(22)
+    assert runtime.require_hw_queues(22, allow_aliasing=True) == 4
+    # HIP initialised before the import with the default queues (the ROS-node shape): the value of THAT moment counts
+    monkeypatch.setattr(de6d_amd, 'HW_QUEUES_AT_IMPORT', 4)
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '24')
+    with pytest.raises(RuntimeError):
+        runtime.require_hw_queues(6)

@@ -21,6 +21,23 @@ def test_nms_against_reference_iou3d_cpu(oracle_ops):
             np.testing.assert_array_equal(oracle_ops.nms_from_iou(iou, thr), want)
 
 
+def test_nms_random_sets_with_near_threshold_pairs(oracle_ops):
+    """24 sets of random size K in [1, 1024] whose boxes include engineered near-threshold partners (the reference's own IoUs
+    come within 1e-7 .. 1e-4 of the thresholds: `rmargin_*`): keep lists of the reference's iou3d_cpu.cpp + greedy scan"""
+    z = np.load(os.path.join(G, 'nms_ref.npz'))
+    sizes = z['random_sizes']
+    assert len(sizes) >= 20 and sizes.max() == 1024 and sizes.min() == 1
+    tight = 0
+    for c, k in enumerate(sizes):
+        boxes = z['rboxes_%d' % c]
+        assert boxes.shape == (k, 7)
+        for thr in (0.01, 0.1, 0.7):
+            tag = str(thr).replace('.', 'p')
+            np.testing.assert_array_equal(oracle_ops.nms(boxes, thr), z['rkeep_%d_%s' % (c, tag)], err_msg='set %d thr %s' % (c, thr))
+            tight += float(z['rmargin_%d_%s' % (c, tag)]) < 2e-5
+    assert tight >= 40          # most (set, threshold) cases hold a pair closer to the threshold than the IoU tolerance
+
+
 def test_nms_mask_layout_matches_greedy(oracle_ops):
     z = np.load(os.path.join(G, 'nms_ref.npz'))
     boxes = z['boxes_65']

@@ -25,6 +25,28 @@ def oracle_of(cfg, model, pts_np, b):
     return omodel.forward(cfg.MODEL, sd, pts_np, b)
 
 
+def test_pipelined_tests_run_on_the_benchmarked_queues():
+    """round-4 review: the ScenePipeline-vs-oracle tests below ran on the default 4 hardware queues (22 streams aliased and
+    serialised) while bench.py times 24.  tests/conftest.py exports GPU_MAX_HW_QUEUES=24 before anything initialises HIP;
+    and a process that initialised HIP FIRST with the default queues gets a RuntimeError from ScenePipeline, not a warning."""
+    import de6d_amd
+    assert de6d_amd.HW_QUEUES_AT_IMPORT is None and int(os.environ['GPU_MAX_HW_QUEUES']) >= 24
+    code = (
+        "import os, sys; os.environ.pop('GPU_MAX_HW_QUEUES', None); sys.path.insert(0, %r)\n"
+        "import torch; torch.zeros(1, device='cuda'); torch.cuda.synchronize()      # the caller's own context first\n"
+        "import de6d_amd; assert de6d_amd.HW_QUEUES_AT_IMPORT == 4\n"
+        "from de6d_amd.runtime import load_config, build_model, ScenePipeline\n"
+        "cfg = load_config('synthetic_models/det6d_tiny.yaml'); model = build_model(cfg, seed=3, device='cuda')\n"
+        "try:\n"
+        "    ScenePipeline(model, 2, 2048, n_main=16, group=4, prefetch=4, sampler_streams=6)\n"
+        "except RuntimeError as e:\n"
+        "    assert 'GPU_MAX_HW_QUEUES' in str(e); print('raised')\n"
+        "pipe = ScenePipeline(model, 2, 2048, n_main=2, group=1, prefetch=1, sampler_streams=1)   # 3 streams fit 4 queues\n"
+        "print('small ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'raised' in out.stdout and 'small ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_bench_group_full_size_vs_oracle(oracle_ops):
     """the benchmarked shape: Det6DGroup(k=4), batch 8 x 16384, four DIFFERENT batches; every pass against the oracle:
     sampled points of every level, features, logits, boxes, kept detections and their order — bit-exact"""
