@@ -13,7 +13,7 @@ LIB = os.path.join(CSRC, "libdet6d_hip.so")
 SOURCES = ["runtime.hip", "fps.hip", "fps_cells.hip", "fps_seq.hip", "fps_coop.hip", "ball_query.hip", "ball_query_grid.hip", "points.hip", "iou3d_nms.hip", "iou3d_host.hip", "linear.hip", "mlp_chain.hip", "mlp_group.hip", "mlp_rows.hip", "compact.hip", "expand.hip", "prepare.hip", "annos.hip", "slope.hip", "kitti_eval.hip"]
 #: kernels that exist only in the -DDET6D_EXPERIMENTS library (measured alternatives that did not earn their place)
 EXPERIMENT_SOURCES = []
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fps_multi.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fps_multi.h"), os.path.join(CSRC, "compact_parts.h"),
            os.path.join(HERE, "..", "include", "det6d_ops.h"),
            os.path.join(HERE, "..", "include", "det6d_math.h"),
            os.path.join(HERE, "..", "include", "det6d_geom.h"),

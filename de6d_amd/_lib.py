@@ -66,6 +66,8 @@ _SIGNATURES = {
     "det6d_ball_query_dilated": [c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P],
     "det6d_ball_query_pair": [c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P],
     "det6d_ball_query_pair_grid": [c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
+    "det6d_ball_query_pair_grid_lists": [c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                         c_int, c_int, _P, _P, _P],
     "det6d_group_points": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_group_points_grad": [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "det6d_three_nn": [c_int, c_int, c_int, _P, _P, _P, _P, _P],
@@ -90,6 +92,8 @@ _SIGNATURES = {
                                  _P, c_int, _P, c_int, c_int, _P],
     "det6d_compact_groups_pair": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P,
                                   _P, c_int, c_int, _P, c_int, _P],
+    "det6d_compact_groups_pair_counted": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P,
+                                          _P, c_int, c_int, _P, c_int, _P],
     "det6d_compact_groups": [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "det6d_mlp_group3_supported": [c_int, c_int, c_int, c_int, c_int],
     "det6d_mlp_group3": [c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,

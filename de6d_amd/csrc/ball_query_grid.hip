@@ -15,6 +15,7 @@
 // Grid build: one workgroup per scene; cell counts / cursors live in LDS (<= 128 x 128 cells; when
 // the scene is larger than 128 cells across, the cell edge grows instead — still >= the radius).
 #include "common.h"
+#include "compact_parts.h"
 
 namespace {
 
@@ -156,84 +157,267 @@ __device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restr
   return keep;
 }
 
-// One wave per centre.  The reference's contract is "the first nsample hits by ASCENDING POINT INDEX", but the grid hands
-// out candidates in spatial order, so per shell the wave keeps a running selection of the nsample smallest hit indices:
-// hits are appended, unordered, to a kListCap-entry LDS list through ballots; when the list would overflow it is cut back
-// to its nsample smallest entries and the largest of them becomes a THRESHOLD — a later hit with a larger index can never
-// be among the first nsample and is dropped before it is stored.  After the first cut the list holds >= nsample entries for
-// good, so the hit count min(total, nsample) is known without counting the dropped hits.  On FPS-sampled clouds a shell has
-// a handful of hits and the list is ranked once, at the end; in the dense parts of a real sweep (hundreds of hits in the
-// 0.8 m shell of the first SA layer) a cut happens once or twice per centre.  (Round 2 re-scanned such centres into an
-// N-bit LDS bitmap per wave and read it back in index order: 273 us for SA1 on ray-cast scenes against 31 us on uniform
-// ones; bit-identical results.)
+// ---- the query ---------------------------------------------------------------------------------------------------------
+// The reference's contract is "the first nsample hits by ASCENDING POINT INDEX", but the grid hands out candidates in spatial
+// order, so per shell a centre keeps the nsample smallest hit indices seen so far.
+//
+// Round 5: a workgroup owns 256 CONSECUTIVE centres of one scene, one per lane.  On FPS-sampled clouds a centre's 3 x 3 cells
+// hold ~20 candidates; the round-2..4 kernel gave every centre a whole wave (three 64-lane sweeps with ~6 live lanes each,
+// two ballots, two list rankings: ~275 vector instructions per centre, 49 M per 32-scene pass — the largest vector-ALU
+// consumer beside the fp32 MFMAs it shares the issue port with).  Now
+//   LIGHT centres (<= kLightCap candidates): the lane walks its own candidates one by one and keeps its hits SORTED in a
+//     per-lane LDS list (insertion from the back: candidates of a cell arrive nearly in index order);
+//   HEAVY centres (dense parts of a real sweep: hundreds of candidates): the wave takes them one at a time, lane =
+//     candidate, exactly as before (running selection in a kListCap-entry list, pruning threshold, ranked at the end);
+//   OUTPUT: the wave writes its 64 centres' index rows as 16-byte stores out of the lane lists (cyclic padding as the
+//     reference writes it: ball_query_gpu.cu:75-90,114-129), and — when the caller builds compact row lists from the result
+//     (compact.hip) — the workgroup leaves the per-class part counts of its 256 centres in the list builder's table, which
+//     saves that builder's counting launch.
 constexpr int kListCap = 128;
+constexpr int kLaneThreads = 256;
+constexpr int kLightCap = 48;
 
-__global__ __launch_bounds__(64 * kQueryWaves) void bq_grid_query_kernel(
-    int n, int m, float rin2_a, float rout2_a, int ns_a, float rin2_b, float rout2_b, int ns_b,
-    const float *__restrict__ new_xyz, const GridHeader *__restrict__ hdr,
-    const int *__restrict__ cell_start, const float4 *__restrict__ sorted_pts, int *__restrict__ cnt_a,
-    int *__restrict__ idx_a, int *__restrict__ cnt_b, int *__restrict__ idx_b) {
-  __shared__ int lists[kQueryWaves][2][kListCap];
-  __shared__ int tmp[kQueryWaves][kMaxNs];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bs = blockIdx.y;
-  const GridHeader h = hdr[bs];
-  const int *cs = cell_start + (size_t)bs * (kGridCells + 1);
-  const float4 *si = sorted_pts + (size_t)bs * n;
-  int *la = lists[wave][0], *lb = lists[wave][1], *tw = tmp[wave];
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One wave, one centre (wave-uniform arguments): both shells' hit lists in la / lb (ascending, <= ns entries), counts returned.
+// Hits are appended, unordered, through ballots; when a list would overflow it is cut back to its nsample smallest entries and
+// the largest of them becomes a THRESHOLD — a later hit with a larger index can never be among the first nsample and is
+// dropped before it is stored.  After the first cut the list holds >= nsample entries for good, so min(total, nsample) is
+// known without counting the dropped hits.
+__device__ __forceinline__ void wave_centre_scan(float qx, float qy, float qz, const int (&beg)[3], const int (&end)[3],
+                                                 float rin2_a, float rout2_a, int ns_a, float rin2_b, float rout2_b, int ns_b,
+                                                 const float4 *__restrict__ si, int *__restrict__ la, int *__restrict__ lb,
+                                                 int *__restrict__ tw, int lane, int &cnt_a, int &cnt_b) {
   const unsigned long long below = (1ull << lane) - 1ull;
+  int na = 0, nb = 0;                              // entries in the lists (wave-uniform)
+  int thr_a = 0x7fffffff, thr_b = 0x7fffffff;      // only hits with a smaller point index can still be among the first nsample
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    for (int t0 = beg[r]; t0 < end[r]; t0 += 64) {
+      const int t = t0 + lane;
+      bool ha = false, hb = false;
+      int k = 0;
+      if (t < end[r]) {
+        const float4 c = si[t];
+        k = __float_as_int(c.w);
+        const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
+        ha = d2 >= rin2_a && d2 < rout2_a && k < thr_a;
+        hb = d2 >= rin2_b && d2 < rout2_b && k < thr_b;
+      }
+      unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+      if (na + __popcll(ma) > kListCap) {          // wave-uniform: cut the list back to its ns_a smallest entries
+        na = keep_smallest(la, tw, na, ns_a, lane);
+        thr_a = la[ns_a - 1];                      // na == ns_a here (the list held more than 64 >= ns_a entries)
+        ha = ha && k < thr_a;
+        ma = __ballot(ha);
+      }
+      if (nb + __popcll(mb) > kListCap) {
+        nb = keep_smallest(lb, tw, nb, ns_b, lane);
+        thr_b = lb[ns_b - 1];
+        hb = hb && k < thr_b;
+        mb = __ballot(hb);
+      }
+      if (ha) la[na + __popcll(ma & below)] = k;
+      if (hb) lb[nb + __popcll(mb & below)] = k;
+      na += __popcll(ma);
+      nb += __popcll(mb);
+    }
+  }
+  cnt_a = keep_smallest(la, tw, na, ns_a, lane);   // = min(total hits, ns)
+  cnt_b = keep_smallest(lb, tw, nb, ns_b, lane);
+}
 
-  for (int ci = blockIdx.x * kQueryWaves + wave; ci < m; ci += gridDim.x * kQueryWaves) {
-    const float *q = new_xyz + ((size_t)bs * m + ci) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
+// a lane's sorted list lives at L[i * kLaneThreads] (i = 0 .. ns - 1; the caller has added its thread index): every lane of a
+// wave touches its own bank whatever its i.  `last` = the largest kept entry once the list is full.
+template <typename LT>
+__device__ __forceinline__ void lane_insert(LT *__restrict__ L, int &cnt, int &last, int ns, int k) {
+  int pos;
+  if (cnt == ns) {
+    if (k > last) return;                          // not among the ns smallest
+    pos = ns - 1;                                  // replaces the largest
+  } else {
+    pos = cnt++;
+  }
+  while (pos > 0) {
+    const int v = (int)L[(pos - 1) * kLaneThreads];
+    if (v < k) break;
+    L[pos * kLaneThreads] = (LT)v;
+    --pos;
+  }
+  L[pos * kLaneThreads] = (LT)k;
+  if (cnt == ns) last = (int)L[(ns - 1) * kLaneThreads];
+}
+
+struct QueryArgs {
+  int n, m;
+  float rin2_a, rout2_a;
+  int ns_a;
+  float rin2_b, rout2_b;
+  int ns_b;
+  const float *new_xyz;
+  const GridHeader *hdr;
+  const int *cell_start;
+  const float4 *sorted_pts;
+  int *cnt[2], *idx[2];
+  CompactCountArgs count[2];
+};
+
+// l mod c for 0 <= l < 4096, 1 <= c <= 64 (rc ~ 1 / c): the quotient estimate is exact or one short
+__device__ __forceinline__ int small_mod(int l, int c, float rc) {
+  const int q = (int)((float)l * rc);
+  const int r = l - q * c;
+  return r >= c ? r - c : r;
+}
+
+template <typename LT, bool PAD>
+__global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const QueryArgs qa) {
+  extern __shared__ __align__(16) unsigned char lane_lists_raw[];     // (ns_a + ns_b) x 256 entries
+  __shared__ int lists[kLaneThreads / 64][2][kListCap];
+  __shared__ int tmp[kLaneThreads / 64][kMaxNs];
+  __shared__ int cnts[2][kLaneThreads];
+  __shared__ int acc[2][kCompactClasses + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bs = blockIdx.y, n = qa.n, m = qa.m, ns_a = qa.ns_a, ns_b = qa.ns_b;
+  const GridHeader h = qa.hdr[bs];
+  const int *cs = qa.cell_start + (size_t)bs * (kGridCells + 1);
+  const float4 *si = qa.sorted_pts + (size_t)bs * n;
+  LT *LA = reinterpret_cast<LT *>(lane_lists_raw) + tid, *LB = LA + (size_t)ns_a * kLaneThreads;
+  const int ci = blockIdx.x * kLaneThreads + tid;
+  const bool valid = ci < m;
+  if (tid <= kCompactClasses) { acc[0][tid] = 0; acc[1][tid] = 0; }
+
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int beg[3] = {0, 0, 0}, end[3] = {0, 0, 0};
+  if (valid) {
+    const float *q = qa.new_xyz + ((size_t)bs * m + ci) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
     const int cx = cell_coord(qx, h.ox, h.inv_cell, h.nx), cy = cell_coord(qy, h.oy, h.inv_cell, h.ny);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.nx - 1);
-    const int y0 = max(cy - 1, 0), y1 = min(cy + 1, h.ny - 1);
-    int na = 0, nb = 0;                              // entries in the lists (wave-uniform)
-    int thr_a = 0x7fffffff, thr_b = 0x7fffffff;      // only hits with a smaller point index can still be among the first nsample
-    for (int y = y0; y <= y1; ++y) {
-      const int beg = cs[y * h.nx + x0], end = cs[y * h.nx + x1 + 1];   // x-contiguous cells: one range
-      for (int t0 = beg; t0 < end; t0 += 64) {
-        const int t = t0 + lane;
-        bool ha = false, hb = false;
-        int k = 0;
-        if (t < end) {
-          const float4 c = si[t];
-          k = __float_as_int(c.w);
-          const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
-          ha = d2 >= rin2_a && d2 < rout2_a && k < thr_a;
-          hb = d2 >= rin2_b && d2 < rout2_b && k < thr_b;
-        }
-        unsigned long long ma = __ballot(ha), mb = __ballot(hb);
-        if (na + __popcll(ma) > kListCap) {          // wave-uniform: cut the list back to its ns_a smallest entries
-          na = keep_smallest(la, tw, na, ns_a, lane);
-          thr_a = la[ns_a - 1];                      // na == ns_a here (the list held more than 64 >= ns_a entries)
-          ha = ha && k < thr_a;
-          ma = __ballot(ha);
-        }
-        if (nb + __popcll(mb) > kListCap) {
-          nb = keep_smallest(lb, tw, nb, ns_b, lane);
-          thr_b = lb[ns_b - 1];
-          hb = hb && k < thr_b;
-          mb = __ballot(hb);
-        }
-        if (ha) la[na + __popcll(ma & below)] = k;
-        if (hb) lb[nb + __popcll(mb & below)] = k;
-        na += __popcll(ma);
-        nb += __popcll(mb);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int y = cy - 1 + r;
+      if (y >= 0 && y < h.ny) { beg[r] = cs[y * h.nx + x0]; end[r] = cs[y * h.nx + x1 + 1]; }   // x-contiguous cells: one range
+    }
+  }
+  const int n0 = end[0] - beg[0], n01 = n0 + end[1] - beg[1], cand = n01 + end[2] - beg[2];
+  const bool heavy = cand > kLightCap;
+  const int walk = heavy ? 0 : cand;
+  int ca = 0, cb = 0, last_a = 0x7fffffff, last_b = 0x7fffffff;
+
+  // ---- light centres: lane = centre, one candidate per step, the next one's record already in flight
+  {
+    const float rin2_a = qa.rin2_a, rout2_a = qa.rout2_a, rin2_b = qa.rin2_b, rout2_b = qa.rout2_b;
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (0 < walk) nxt = si[0 < n0 ? beg[0] : (0 < n01 ? beg[1] - n0 : beg[2] - n01)];
+    for (int j = 0; __ballot(j < walk) != 0ull; ++j) {
+      const float4 c = nxt;
+      const int j1 = j + 1;
+      if (j1 < walk) nxt = si[j1 < n0 ? beg[0] + j1 : (j1 < n01 ? beg[1] + (j1 - n0) : beg[2] + (j1 - n01))];
+      if (j < walk) {
+        const int k = __float_as_int(c.w);
+        const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
+        if (d2 >= rin2_a && d2 < rout2_a) lane_insert<LT>(LA, ca, last_a, ns_a, k);
+        if (d2 >= rin2_b && d2 < rout2_b) lane_insert<LT>(LB, cb, last_b, ns_b, k);
       }
     }
+  }
+
+  // ---- heavy centres of this wave, one at a time: lane = candidate
+  {
+    int *la = lists[wave][0], *lb = lists[wave][1], *tw = tmp[wave];
+    unsigned long long hm = __ballot(heavy);
+    while (hm != 0ull) {
+      const int src = __builtin_ctzll(hm);
+      hm &= hm - 1ull;
+      int hb[3], he[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { hb[r] = __builtin_amdgcn_readlane(beg[r], src); he[r] = __builtin_amdgcn_readlane(end[r], src); }
+      int wa, wb;
+      wave_centre_scan(d6_readlane_f(qx, src), d6_readlane_f(qy, src), d6_readlane_f(qz, src), hb, he, qa.rin2_a, qa.rout2_a, ns_a,
+                       qa.rin2_b, qa.rout2_b, ns_b, si, la, lb, tw, lane, wa, wb);
+      LT *ca_col = reinterpret_cast<LT *>(lane_lists_raw) + (wave * 64 + src);
+      if (lane < wa) ca_col[lane * kLaneThreads] = (LT)la[lane];                                   // ns <= 64: one entry per lane
+      if (lane < wb) ca_col[(size_t)(ns_a + lane) * kLaneThreads] = (LT)lb[lane];
+      if (lane == src) { ca = wa; cb = wb; }
+      wave_lds_sync();                             // the wave lists are rewritten by the next heavy centre
+    }
+  }
+  cnts[0][tid] = ca;
+  cnts[1][tid] = cb;
+  if (valid) { qa.cnt[0][(size_t)bs * m + ci] = ca; qa.cnt[1][(size_t)bs * m + ci] = cb; }
+  wave_lds_sync();
+
+  // ---- output: this wave's 64 centres, index rows out of the lane lists (row l of a ball with cnt hits = its hit l mod cnt)
+#pragma unroll
+  for (int sh = 0; sh < 2; ++sh) {
+    const int ns = sh == 0 ? ns_a : ns_b;
+    const LT *Lw = reinterpret_cast<const LT *>(lane_lists_raw) + (sh == 0 ? 0 : (size_t)ns_a * kLaneThreads) + wave * 64;
+    int *out = qa.idx[sh] + ((size_t)bs * m + blockIdx.x * kLaneThreads + wave * 64) * ns;
+    const int live = min(64, m - (blockIdx.x * kLaneThreads + wave * 64));      // centres of this wave that exist (may be <= 0)
+    if ((ns & 3) == 0) {
+      const int gper = ns >> 2;                    // 16-byte groups per centre
+      const float rg = __builtin_amdgcn_rcpf((float)gper);
+      for (int it = 0; it < gper; ++it) {
+        const int g = it * 64 + lane;
+        int c = (int)((float)g * rg);              // g / gper, exact or one short (g < 1024)
+        if (g - c * gper >= gper) ++c;
+        const int l0 = (g - c * gper) << 2;
+        const int cnt = cnts[sh][wave * 64 + c];
+        const int cm = max(cnt, 1);
+        const float rc = __builtin_amdgcn_rcpf((float)cm);
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = (int)Lw[small_mod(l0 + u, cm, rc) * kLaneThreads + c];
+          v[u] = cnt > 0 ? e : 0;
+        }
+        // without padding (the caller reads compact rows only: compact.hip walks <= the next power of two >= max(cnt, 4) slots)
+        const int need = cnt <= 4 ? 4 : (1 << (32 - __builtin_clz(cnt - 1)));
+        if (c < live && (PAD || l0 < need)) *reinterpret_cast<int4 *>(out + (size_t)c * ns + l0) = make_int4(v[0], v[1], v[2], v[3]);
+      }
+    } else {                                        // any other nsample: one element per lane and step
+      const float rn = __builtin_amdgcn_rcpf((float)ns);
+      for (int it = 0; it < ns; ++it) {
+        const int e = it * 64 + lane;
+        int c = (int)((float)e * rn);
+        if (e - c * ns >= ns) ++c;
+        const int l = e - c * ns;
+        const int cnt = cnts[sh][wave * 64 + c];
+        const int cm = max(cnt, 1);
+        const int v = (int)Lw[small_mod(l, cm, __builtin_amdgcn_rcpf((float)cm)) * kLaneThreads + c];
+        if (c < live) out[(size_t)c * ns + l] = cnt > 0 ? v : 0;
+      }
+    }
+  }
+
+  // ---- per-class part counts of the 256 centres for the compact list builder (compact.hip: compact_place_kernel)
+  if (qa.count[0].table != nullptr) {              // (uniform; the host passes tables only when m is a multiple of 256)
+    __syncthreads();                               // acc cleared
 #pragma unroll
     for (int sh = 0; sh < 2; ++sh) {
-      int *lst = sh == 0 ? la : lb;
-      const int ns = sh == 0 ? ns_a : ns_b;
-      const int cnt = keep_smallest(lst, tw, sh == 0 ? na : nb, ns, lane);   // = min(total hits, ns): see the header
-      int *out = (sh == 0 ? idx_a : idx_b) + ((size_t)bs * m + ci) * ns;
-      if (lane == 0) (sh == 0 ? cnt_a : cnt_b)[(size_t)bs * m + ci] = cnt;
-      for (int l = lane; l < ns; l += 64) out[l] = cnt > 0 ? lst[l % cnt] : 0;
+      const CompactCountArgs &ct = qa.count[sh];
+      const int k = sh == 0 ? ca : cb;
+      int rows = 0;
+      const int mask = valid ? d6_compact_parts_of(k, ct.ns, ct.smin, ct.split, &rows) : 0;
+      int real = valid ? (k < ct.ns ? k : ct.ns) : 0;
+#pragma unroll
+      for (int cc = 0; cc < kCompactClasses; ++cc) {
+        const int c = __popcll(__ballot((mask >> cc) & 1));
+        if (lane == 0 && c) atomicAdd(&acc[sh][cc], c);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) real += __shfl_xor(real, o);
+      if (lane == 0 && real) atomicAdd(&acc[sh][kCompactClasses], real);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();                 // the lists are rewritten by the next centre
+    __syncthreads();
+    const int bk = bs * gridDim.x + blockIdx.x;
+    if (tid <= kCompactClasses) {
+      qa.count[0].table[bk * (kCompactClasses + 1) + tid] = acc[0][tid];
+      qa.count[1].table[bk * (kCompactClasses + 1) + tid] = acc[1][tid];
+    }
   }
 }
 
@@ -252,15 +436,9 @@ DET6D_API int64_t det6d_ball_query_grid_workspace_bytes(int b, int n) {
   return (int64_t)b * ((per + 63) / 64 * 64) + 256;
 }
 
-DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
-                                         float rout_b, int ns_b, const float *new_xyz, const float *xyz,
-                                         void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
-                                         det6d_stream_t stream) {
-  if (b < 0 || m < 0 || !det6d_ball_query_grid_supported(n, ns_a, ns_b) || !new_xyz || !xyz ||
-      !workspace || ((uintptr_t)workspace & 15) || !cnt_a || !idx_a || !cnt_b || !idx_b)
-    return DET6D_EINVAL;
-  if (b == 0 || m == 0) return DET6D_OK;
-  hipStream_t s = (hipStream_t)stream;
+static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b, float rout_b, int ns_b,
+                             const float *new_xyz, const float *xyz, void *workspace, int *cnt_a, int *idx_a, int *cnt_b,
+                             int *idx_b, bool pad, const CompactCountArgs *count, hipStream_t s, const char *what) {
   // workspace layout: headers | cell_start | sorted (x, y, z, index) records
   char *ws = (char *)workspace;
   GridHeader *hdr = (GridHeader *)ws;
@@ -271,9 +449,58 @@ DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float
   const float rmax = rout_a > rout_b ? rout_a : rout_b;
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start,
                      sorted_pts);
-  const int blocks_x = min(det6d_divup(m, kQueryWaves), 1024);
-  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks_x, b), dim3(64 * kQueryWaves), 0, s, n, m,
-                     rin_a * rin_a, rout_a * rout_a, ns_a, rin_b * rin_b, rout_b * rout_b, ns_b, new_xyz, hdr,
-                     cell_start, sorted_pts, cnt_a, idx_a, cnt_b, idx_b);
-  return det6d_check_launch("det6d_ball_query_pair_grid");
+  QueryArgs qa;
+  qa.n = n; qa.m = m;
+  qa.rin2_a = rin_a * rin_a; qa.rout2_a = rout_a * rout_a; qa.ns_a = ns_a;
+  qa.rin2_b = rin_b * rin_b; qa.rout2_b = rout_b * rout_b; qa.ns_b = ns_b;
+  qa.new_xyz = new_xyz; qa.hdr = hdr; qa.cell_start = cell_start; qa.sorted_pts = sorted_pts;
+  qa.cnt[0] = cnt_a; qa.cnt[1] = cnt_b; qa.idx[0] = idx_a; qa.idx[1] = idx_b;
+  for (int g = 0; g < 2; ++g) qa.count[g] = count ? count[g] : CompactCountArgs{0, 0, 0, nullptr};
+  // index rows leave as 16-byte stores when nsample is a multiple of 4 (idx rows are then 16-byte aligned like their buffers)
+  if (((ns_a & 3) == 0 && ((uintptr_t)idx_a & 15)) || ((ns_b & 3) == 0 && ((uintptr_t)idx_b & 15))) return DET6D_EINVAL;
+  const bool narrow = n <= 65536;                  // point indices fit 16 bits: half the LDS per workgroup
+  const size_t lds = (size_t)(ns_a + ns_b) * kLaneThreads * (narrow ? 2 : 4);
+  const dim3 grid(det6d_divup(m, kLaneThreads), b), block(kLaneThreads);
+#define D6_BQ_LAUNCH(LT, PAD)                                                               \
+  do {                                                                                      \
+    DET6D_MAX_DYNAMIC_LDS((bq_grid_query_kernel<LT, PAD>), 2 * kMaxNs * kLaneThreads * 4);   \
+    hipLaunchKernelGGL((bq_grid_query_kernel<LT, PAD>), grid, block, lds, s, qa);            \
+  } while (0)
+  if (narrow) { if (pad) D6_BQ_LAUNCH(unsigned short, true); else D6_BQ_LAUNCH(unsigned short, false); }
+  else { if (pad) D6_BQ_LAUNCH(int, true); else D6_BQ_LAUNCH(int, false); }
+#undef D6_BQ_LAUNCH
+  return det6d_check_launch(what);
+}
+
+DET6D_API int det6d_ball_query_pair_grid(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
+                                         float rout_b, int ns_b, const float *new_xyz, const float *xyz,
+                                         void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
+                                         det6d_stream_t stream) {
+  if (b < 0 || m < 0 || !det6d_ball_query_grid_supported(n, ns_a, ns_b) || !new_xyz || !xyz ||
+      !workspace || ((uintptr_t)workspace & 15) || !cnt_a || !idx_a || !cnt_b || !idx_b)
+    return DET6D_EINVAL;
+  if (b == 0 || m == 0) return DET6D_OK;
+  return launch_grid_query(b, n, m, rin_a, rout_a, ns_a, rin_b, rout_b, ns_b, new_xyz, xyz, workspace, cnt_a, idx_a, cnt_b,
+                           idx_b, true, nullptr, (hipStream_t)stream, "det6d_ball_query_pair_grid");
+}
+
+// Engine form (fused section of the header): the same query feeding det6d_compact_groups_pair_counted.  Index rows are written
+// only as far as the compact list builder reads them (slots below the next power of two >= max(cnt, 4), cyclic padding
+// included), and the builder's per-block part counts are left in hdr_a / hdr_b (m must be a multiple of 256).
+DET6D_API int det6d_ball_query_pair_grid_lists(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
+                                               float rout_b, int ns_b, const float *new_xyz, const float *xyz,
+                                               void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
+                                               int smin, int split, int *hdr_a, int *hdr_b, det6d_stream_t stream) {
+  if (b < 0 || m < 0 || !det6d_ball_query_grid_supported(n, ns_a, ns_b) || !new_xyz || !xyz ||
+      !workspace || ((uintptr_t)workspace & 15) || !cnt_a || !idx_a || !cnt_b || !idx_b || !hdr_a || !hdr_b)
+    return DET6D_EINVAL;
+  if (m % kLaneThreads != 0 || smin < 1 || smin > 4 || (smin & (smin - 1))) return DET6D_EINVAL;
+  if (b == 0 || m == 0) return DET6D_OK;
+  int sa = split, sb = split;
+  const int smin_a = smin < ns_a ? smin : ns_a, smin_b = smin < ns_b ? smin : ns_b;
+  if (det6d_compact_check_group(ns_a, smin_a, &sa) || det6d_compact_check_group(ns_b, smin_b, &sb)) return DET6D_EINVAL;
+  const CompactCountArgs count[2] = {{ns_a, smin_a, det6d_compact_split_tol(sa), hdr_a + 16},
+                                     {ns_b, smin_b, det6d_compact_split_tol(sb), hdr_b + 16}};
+  return launch_grid_query(b, n, m, rin_a, rout_a, ns_a, rin_b, rout_b, ns_b, new_xyz, xyz, workspace, cnt_a, idx_a, cnt_b,
+                           idx_b, false, count, (hipStream_t)stream, "det6d_ball_query_pair_grid_lists");
 }

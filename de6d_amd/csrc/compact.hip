@@ -19,35 +19,14 @@
 //   crow_c[r]   centre (scene * m + j) row r belongs to, bit 30 set when its ball is empty (pooled value = 0:
 //               pointnet2_modules.py:465-467), -1 for alignment rows (computed, never stored)
 #include "common.h"
+#include "compact_parts.h"
 
 namespace {
 
-constexpr int kClasses = 6;
+constexpr int kClasses = kCompactClasses;
 
-// classes (bit c <-> s = 32 >> c) the rows of a centre with `cnt` hits are placed in.
-//   split = 0: one part, the next power of two >= max(cnt, smin);
-//   split = g > 0: up to g hits the same single part; beyond, ceil(cnt / g) * g rows, cut along their binary digits
-//              into parts of descending size (20 rows = 16 + 4: slots 0..15 form a class-16 group, slots 16..19 a
-//              class-4 group); the pooled value of the centre is the maximum over its parts, combined by an integer
-//              atomic max on the (non-negative, post-ReLU) outputs (bit 29 of crow_c marks such rows; the pooled
-//              buffer is zeroed first).  smin = 1, g = 4: singles and pairs are rows of their own, no atomics for them.
 __device__ __forceinline__ int parts_of(int cnt, int ns, int smin, int split_tol, int *rows_out) {
-  const int k = cnt < 1 ? 1 : (cnt > ns ? ns : cnt);
-  const int split = split_tol & 0xff, tol = split_tol >> 8;   // tol t > 0: one power-of-two part when it wastes <= 1/t of its rows
-  int p2 = smin;
-  while (p2 < k) p2 <<= 1;
-  int rows;
-  if (split > 0 && k > split && !(tol > 0 && (p2 - k) * tol <= p2)) {
-    rows = (k + split - 1) / split * split;
-  } else {
-    rows = p2;
-  }
-  *rows_out = rows;
-  int mask = 0;
-#pragma unroll
-  for (int c = 0; c < kClasses; ++c)
-    if (rows & (32 >> c)) mask |= 1 << c;
-  return mask;
+  return d6_compact_parts_of(cnt, ns, smin, split_tol, rows_out);
 }
 
 // pass 1: parts per class (and information rows) of every block of 256 centres -> table[block][kClasses + 1]
@@ -228,9 +207,7 @@ DET6D_API int det6d_compact_rows_capacity(int total_centres, int ns) {
 
 DET6D_API int det6d_compact_hdr_ints(int total_centres) { return 16 + (kClasses + 1) * (det6d_divup(total_centres, 256) + 1); }
 
-static int check_group(int ns, int smin, int *split, const int *cnt, const int *idx, const int *hdr, const int *crow_p,
-                       const int *crow_c) {
-  if (!cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
+int det6d_compact_check_group(int ns, int smin, int *split) {
   if (ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16 && ns != 32) return DET6D_EINVAL;
   if (smin < 1 || smin > ns || (smin & (smin - 1))) return DET6D_EINVAL;
   if (*split < 0 || (*split & (*split - 1)) || (*split && *split < smin)) return DET6D_EINVAL;
@@ -238,14 +215,27 @@ static int check_group(int ns, int smin, int *split, const int *cnt, const int *
   return DET6D_OK;
 }
 
-static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa_in, float *zero_y, int ldy, hipStream_t stream) {
+int det6d_compact_split_tol(int split) {
   // experiment knob: DET6D_COMPACT_TOL=t keeps a centre in ONE power-of-two part when that wastes <= 1/t of its rows
   static const int tol = det6d_env_int("DET6D_COMPACT_TOL", 0);
+  return tol > 0 ? split | (tol << 8) : split;
+}
+
+static int check_group(int ns, int smin, int *split, const int *cnt, const int *idx, const int *hdr, const int *crow_p,
+                       const int *crow_c) {
+  if (!cnt || !idx || !hdr || !crow_p || !crow_c) return DET6D_EINVAL;
+  return det6d_compact_check_group(ns, smin, split);
+}
+
+static int launch_groups(int b, int n, int m, int ngroups, const PairArgs &pa_in, float *zero_y, int ldy, hipStream_t stream,
+                         bool counted = false) {
   PairArgs pa = pa_in;
-  if (tol > 0) { pa.g[0].split |= tol << 8; pa.g[1].split |= tol << 8; }
+  pa.g[0].split = det6d_compact_split_tol(pa.g[0].split);
+  pa.g[1].split = det6d_compact_split_tol(pa.g[1].split);
   const int total = b * m;
   const int nblk = det6d_divup(total, 256) > 0 ? det6d_divup(total, 256) : 1;
-  hipLaunchKernelGGL(compact_count_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, pa);
+  // counted: the per-block part counts are in the tables already (det6d_ball_query_pair_grid_lists leaves them there)
+  if (!counted) hipLaunchKernelGGL(compact_count_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, pa);
   hipLaunchKernelGGL(compact_place_kernel, dim3(nblk, ngroups), dim3(256), 0, stream, total, n, m, nblk, zero_y, ldy, pa);
   return det6d_check_launch("det6d_compact_groups");
 }
@@ -263,10 +253,10 @@ DET6D_API int det6d_compact_groups(int b, int n, int m, int ns, int smin, int sp
 }
 
 // both radius groups of an SA layer (same centres, their own nsample / counts / indices / lists) in one pair of launches
-DET6D_API int det6d_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
-                                        int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
-                                        const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
-                                        int width_b, float *zero_y, int ldy, det6d_stream_t stream) {
+static int groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
+                       int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
+                       const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
+                       int width_b, float *zero_y, int ldy, det6d_stream_t stream, bool counted) {
   if (b < 0 || n <= 0 || m <= 0) return DET6D_EINVAL;
   int sa = split, sb = split;
   const int smin_a = smin < ns_a ? smin : ns_a, smin_b = smin < ns_b ? smin : ns_b;
@@ -280,5 +270,25 @@ DET6D_API int det6d_compact_groups_pair(int b, int n, int m, int smin, int split
   PairArgs pa;
   pa.g[0] = GroupArgs{ns_a, smin_a, sa, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a, col0_a, width_a};
   pa.g[1] = GroupArgs{ns_b, smin_b, sb, cnt_b, idx_b, hdr_b, crow_p_b, crow_c_b, col0_b, width_b};
-  return launch_groups(b, n, m, 2, pa, zero_y, ldy, (hipStream_t)stream);
+  return launch_groups(b, n, m, 2, pa, zero_y, ldy, (hipStream_t)stream, counted);
+}
+
+DET6D_API int det6d_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
+                                        int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
+                                        const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
+                                        int width_b, float *zero_y, int ldy, det6d_stream_t stream) {
+  return groups_pair(b, n, m, smin, split, ns_a, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a, col0_a, width_a, ns_b, cnt_b, idx_b, hdr_b,
+                     crow_p_b, crow_c_b, col0_b, width_b, zero_y, ldy, stream, false);
+}
+
+// the list builder behind det6d_ball_query_pair_grid_lists(smin, split, hdr_a, hdr_b), which has left the per-block part counts
+// in the two hdr buffers: placement only.  m must be a multiple of 256 (the query's workgroups are the builder's blocks).
+DET6D_API int det6d_compact_groups_pair_counted(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a,
+                                                const int *idx_a, int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a,
+                                                int ns_b, const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b,
+                                                int *crow_c_b, int col0_b, int width_b, float *zero_y, int ldy,
+                                                det6d_stream_t stream) {
+  if (m % 256 != 0) return DET6D_EINVAL;
+  return groups_pair(b, n, m, smin, split, ns_a, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a, col0_a, width_a, ns_b, cnt_b, idx_b, hdr_b,
+                     crow_p_b, crow_c_b, col0_b, width_b, zero_y, ldy, stream, true);
 }

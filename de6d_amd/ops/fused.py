@@ -193,13 +193,18 @@ def _alloc_lists(b, m, ns, device):
                        torch.empty((cap,), dtype=torch.int32, device=device), cap, ns)
 
 
-def compact_groups_pair(found, n, pooled, cols):
-    """both radius groups of an SA layer: found = [(cnt, idx)] x 2, cols = [(col0, width)] x 2 of `pooled` (cleared)"""
+def compact_groups_pair(found, n, pooled, cols, counted=None):
+    """both radius groups of an SA layer: found = [(cnt, idx)] x 2, cols = [(col0, width)] x 2 of `pooled` (cleared).
+    counted = the two CompactRows ball_query_pair_lists() has left the per-block part counts in: placement only"""
     (ca, ia), (cb, ib) = found
     L.require_cuda(ca, ia, cb, ib, pooled)
     b, m, _ = ia.shape
-    la, lb = _alloc_lists(b, m, ia.shape[2], ia.device), _alloc_lists(b, m, ib.shape[2], ib.device)
-    L.call("det6d_compact_groups_pair", b, n, m, COMPACT_SMIN, COMPACT_SPLIT, ia.shape[2], L.ptr(ca), L.ptr(ia), L.ptr(la.hdr),
+    if counted is not None:
+        la, lb = counted
+    else:
+        la, lb = _alloc_lists(b, m, ia.shape[2], ia.device), _alloc_lists(b, m, ib.shape[2], ib.device)
+    L.call("det6d_compact_groups_pair_counted" if counted is not None else "det6d_compact_groups_pair",
+           b, n, m, COMPACT_SMIN, COMPACT_SPLIT, ia.shape[2], L.ptr(ca), L.ptr(ia), L.ptr(la.hdr),
            L.ptr(la.crow_p), L.ptr(la.crow_c), cols[0][0], cols[0][1], ib.shape[2], L.ptr(cb), L.ptr(ib), L.ptr(lb.hdr),
            L.ptr(lb.crow_p), L.ptr(lb.crow_c), cols[1][0], cols[1][1], L.ptr(pooled), pooled.shape[-1], L.stream_ptr())
     return [la, lb]
@@ -472,6 +477,32 @@ def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
            float(shell_b[1]), shell_b[2], L.ptr(new_xyz), L.ptr(xyz), L.ptr(cnt_a), L.ptr(idx_a), L.ptr(cnt_b),
            L.ptr(idx_b), L.stream_ptr())
     return cnt_a, idx_a, cnt_b, idx_b
+
+
+def ball_query_pair_lists(xyz, new_xyz, shell_a, shell_b):
+    """The grid query as the compact-row engine uses it (csrc/ball_query_grid.hip: det6d_ball_query_pair_grid_lists): same
+    hits and counts as ball_query_pair(); index rows written only as far as the list builder reads them (no padding beyond
+    the next power of two >= max(cnt, 4)), and the builder's per-block part counts left in the two CompactRows it returns
+    — compact_groups_pair(..., counted=them) then only places.  Returns None when the shape does not qualify (small clouds,
+    m not a multiple of 256, nsample not 4 / 8 / 16 / 32): callers use ball_query_pair() + compact_groups_pair()."""
+    L.require_cuda(xyz, new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    dev = xyz.device
+    ns_a, ns_b = shell_a[2], shell_b[2]
+    if (n < GRID_QUERY_MIN_N or m % 256 or not COMPACT_SPLIT or COMPACT_SMIN > 4 or not all(ns in (4, 8, 16, 32) for ns in (ns_a, ns_b))
+            or not L.lib().det6d_ball_query_grid_supported(n, ns_a, ns_b)):
+        return None
+    cnt_a = torch.empty((b, m), dtype=torch.int32, device=dev)
+    cnt_b = torch.empty((b, m), dtype=torch.int32, device=dev)
+    idx_a = torch.empty((b, m, ns_a), dtype=torch.int32, device=dev)
+    idx_b = torch.empty((b, m, ns_b), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.lib().det6d_ball_query_grid_workspace_bytes(b, n)),), dtype=torch.uint8, device=dev)
+    la, lb = _alloc_lists(b, m, ns_a, dev), _alloc_lists(b, m, ns_b, dev)
+    L.call("det6d_ball_query_pair_grid_lists", b, n, m, float(shell_a[0]), float(shell_a[1]), ns_a, float(shell_b[0]), float(shell_b[1]),
+           ns_b, L.ptr(new_xyz), L.ptr(xyz), L.ptr(ws), L.ptr(cnt_a), L.ptr(idx_a), L.ptr(cnt_b), L.ptr(idx_b), COMPACT_SMIN,
+           COMPACT_SPLIT, L.ptr(la.hdr), L.ptr(lb.hdr), L.stream_ptr())
+    return cnt_a, idx_a, cnt_b, idx_b, la, lb
 
 
 #: route [68 -> 64 -> 64|96 -> 128] groups through the wide register chain kernel

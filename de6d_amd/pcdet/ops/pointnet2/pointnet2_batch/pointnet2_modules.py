@@ -258,8 +258,18 @@ class _PointnetSAModuleFSBase(nn.Module):
         for radius, nsample in zip(self.radii, self.nsamples):
             shells.append((former_radius if self.dilated_radius_group else 0.0, radius, nsample))
             former_radius = radius
+        counted = None
+        widths = [layers[-1][2] for layers in f['groups']]
         if len(shells) == 2:
-            ca, ia, cb, ib = fused.ball_query_pair(xyz, new_xyz, shells[0], shells[1])
+            fast = None
+            if COMPACT_ROWS and (widths[0] | widths[1] | pooled.shape[1]) % 4 == 0:
+                # compact-row engine on a large cloud: the query counts the list builder's parts and skips the padding slots
+                fast = fused.ball_query_pair_lists(xyz, new_xyz, shells[0], shells[1])
+            if fast is not None:
+                ca, ia, cb, ib = fast[:4]
+                counted = fast[4:]
+            else:
+                ca, ia, cb, ib = fused.ball_query_pair(xyz, new_xyz, shells[0], shells[1])
             found = [(ca, ia), (cb, ib)]
         else:
             found = []
@@ -272,11 +282,10 @@ class _PointnetSAModuleFSBase(nn.Module):
                     pn2.ball_query_cnt_wrapper(b, n, m, rout, nsample, new_xyz, xyz, idx_cnt, idx)
                 found.append((idx_cnt, idx))
         lists = [None] * len(found)
-        widths = [layers[-1][2] for layers in f['groups']]
         if (COMPACT_ROWS and fused.COMPACT_SPLIT and len(found) == 2 and all(ns in (4, 8, 16, 32) for ns in self.nsamples)
                 and (widths[0] | widths[1] | pooled.shape[1]) % 4 == 0):
             # both groups' lists in one pair of launches; their slices of `pooled` are cleared by the builder
-            lists = fused.compact_groups_pair(found, n, pooled, [(0, widths[0]), (widths[0], widths[1])])
+            lists = fused.compact_groups_pair(found, n, pooled, [(0, widths[0]), (widths[0], widths[1])], counted=counted)
         p_all = None
         if f['expand']:   # per-point partial sums of the first layers of all expand groups: one plain GEMM over the points
             p_all = torch.empty((b * n, f['p_w'].shape[1]), dtype=torch.float32, device=rows.device)

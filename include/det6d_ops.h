@@ -91,8 +91,9 @@ int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns
 
 /* Grid-hashed form of det6d_ball_query_pair for large N (identical results): a uniform (x, y) grid
  * with cell edge >= max(rout_a, rout_b) is built per scene, a centre tests only the points of its
- * 3x3 cell neighbourhood and keeps, per shell, the nsample smallest hit indices (a short LDS list with a
- * pruning threshold, ranked once at the end: the reference's ascending-index order).  workspace:
+ * 3x3 cell neighbourhood and keeps, per shell, the nsample smallest hit indices (a centre with few candidates walks them
+ * in one lane with a sorted per-lane list, a centre with many takes a wave: a short LDS list with a pruning threshold,
+ * ranked once at the end: the reference's ascending-index order either way).  workspace:
  * det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.  ns_a, ns_b <= 64
  * (DET6D_EINVAL beyond: use det6d_ball_query_pair).  det6d_ball_query_grid_supported(n, ns_a, ns_b): 1 when this entry takes
  * the shape (the host asks before it routes a query here instead of through det6d_ball_query_pair / _cnt / _dilated, which
@@ -439,6 +440,22 @@ int det6d_compact_groups_pair(int b, int n, int m, int smin, int split, int ns_a
                               int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
                               const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
                               int width_b, float *zero_y, int ldy, det6d_stream_t stream);
+
+/* The grid query as the compact-row engine uses it, and the list builder behind it.
+ * det6d_ball_query_pair_grid_lists: same hits and counts as det6d_ball_query_pair_grid, but (1) index rows are written only as
+ * far as the list builder reads them — the slots below the next power of two >= max(cnt, 4), the reference's cyclic padding
+ * (ball_query_gpu.cu:75-90,114-129) included; the rest of an idx row is left untouched — and (2) every workgroup (256
+ * consecutive centres of a scene) leaves the part counts of its centres in the scratch part of hdr_a / hdr_b, so that
+ * det6d_compact_groups_pair_counted only places rows (one launch less per SA layer).  m must be a multiple of 256, smin <= 4,
+ * ns_a / ns_b in {4, 8, 16, 32}; smin / split as for det6d_compact_groups_pair, to which the pair is equivalent. */
+int det6d_ball_query_pair_grid_lists(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b, float rout_b,
+                                     int ns_b, const float *new_xyz, const float *xyz, void *workspace, int *cnt_a, int *idx_a,
+                                     int *cnt_b, int *idx_b, int smin, int split, int *hdr_a, int *hdr_b,
+                                     det6d_stream_t stream);
+int det6d_compact_groups_pair_counted(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a, const int *idx_a,
+                                      int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a, int width_a, int ns_b,
+                                      const int *cnt_b, const int *idx_b, int *hdr_b, int *crow_p_b, int *crow_c_b, int col0_b,
+                                      int width_b, float *zero_y, int ldy, det6d_stream_t stream);
 
 /* The three pointwise layers of a grouped MLP in one launch, nsample 16 or 32: identical, bit for bit, to
  *   det6d_linear(GROUPED, W1, ReLU) -> det6d_linear(ROWS, W2, ReLU) -> det6d_linear(ROWS, W3, ReLU, pool = ns, cnt)

@@ -610,6 +610,52 @@ ORACLE_API int det6d_oracle_compact_groups_pair(int b, int n, int m, int smin, i
                                      crow_c_b, zero_y, ldy, col0_b, width_b);
 }
 
+/* The engine pair det6d_ball_query_pair_grid_lists + det6d_compact_groups_pair_counted (csrc/ball_query_grid.hip, compact.hip):
+ * the query's hits and counts are the brute-force ones; the contract for the index rows is "slots below the next power of
+ * two >= max(cnt, 4) hold the reference's (cyclically padded) row, the rest is untouched" — the restatement writes exactly
+ * those slots; the per-block part counts go to hdr + 16 as the HIP query leaves them (7 ints per block of 256 centres). */
+ORACLE_API int det6d_oracle_ball_query_pair_grid_lists(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b,
+                                                       float rout_b, int ns_b, const float *new_xyz, const float *xyz,
+                                                       void *workspace, int *cnt_a, int *idx_a, int *cnt_b, int *idx_b,
+                                                       int smin, int split, int *hdr_a, int *hdr_b) {
+  (void)workspace;
+  const int total = b * m;
+  int *full_a = (int *)malloc(sizeof(int) * (size_t)total * ns_a), *full_b = (int *)malloc(sizeof(int) * (size_t)total * ns_b);
+  det6d_oracle_ball_query_pair(b, n, m, rin_a, rout_a, ns_a, rin_b, rout_b, ns_b, new_xyz, xyz, cnt_a, full_a, cnt_b, full_b);
+  for (int g = 0; g < 2; ++g) {
+    const int ns = g ? ns_b : ns_a, *cnt = g ? cnt_b : cnt_a, *full = g ? full_b : full_a;
+    int *idx = g ? idx_b : idx_a, *table = (g ? hdr_b : hdr_a) + 16;
+    const int sm = smin < ns ? smin : ns;
+    int sp = split && split < sm ? sm : split;
+    if (sp > ns) sp = ns;
+    for (int i = 0; i < total; ++i) {
+      int need = 4;
+      while (need < cnt[i]) need <<= 1;
+      for (int l = 0; l < ns && l < need; ++l) idx[(size_t)i * ns + l] = full[(size_t)i * ns + l];
+    }
+    for (int bk = 0; bk * 256 < total; ++bk) {
+      int *t = table + bk * 7;
+      for (int c = 0; c < 7; ++c) t[c] = 0;
+      for (int i = bk * 256; i < total && i < bk * 256 + 256; ++i) {
+        const int rows = compact_rows_of(cnt[i], ns, sm, sp);
+        for (int c = 0; c < 6; ++c) t[c] += (rows & (32 >> c)) != 0;
+        t[6] += cnt[i] < ns ? (cnt[i] < 0 ? 0 : cnt[i]) : ns;
+      }
+    }
+  }
+  free(full_a); free(full_b);
+  return 0;
+}
+ORACLE_API int det6d_oracle_compact_groups_pair_counted(int b, int n, int m, int smin, int split, int ns_a, const int *cnt_a,
+                                                        const int *idx_a, int *hdr_a, int *crow_p_a, int *crow_c_a, int col0_a,
+                                                        int width_a, int ns_b, const int *cnt_b, const int *idx_b, int *hdr_b,
+                                                        int *crow_p_b, int *crow_c_b, int col0_b, int width_b, float *zero_y,
+                                                        int ldy) {
+  /* (the sequential builder counts for itself: the tables only save the parallel builder a launch) */
+  return det6d_oracle_compact_groups_pair(b, n, m, smin, split, ns_a, cnt_a, idx_a, hdr_a, crow_p_a, crow_c_a, col0_a, width_a, ns_b,
+                                          cnt_b, idx_b, hdr_b, crow_p_b, crow_c_b, col0_b, width_b, zero_y, ldy);
+}
+
 /* Order of the fma chain of one output.  Plain rows: k ascending.  GATHERED rows [x - cx, y - cy, z - cz, f_0 ..] (the first
  * layer of a grouped MLP): the feature columns first (k = 3 .. K-1), the three relative coordinates LAST.  The reference's
  * Conv2d over torch.cat([grouped_xyz, grouped_features]) (pointnet2_utils.py:449-455, pointnet2_modules.py:561-568) is a

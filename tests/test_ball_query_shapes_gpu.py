@@ -112,3 +112,70 @@ def test_whole_model_with_any_nsample(oracle_ops):
     for got, want in zip(pred, ref['pred_dicts']):
         np.testing.assert_array_equal(got['pred_boxes'].cpu().numpy(), want['pred_boxes'])
         np.testing.assert_array_equal(got['pred_scores'].cpu().numpy(), want['pred_scores'])
+
+
+@pytest.mark.parametrize("scene", ["uniform", "beam", "blob", "dup"])
+@pytest.mark.parametrize("smin,split", [(1, 1), (4, 4), (2, 4)])
+def test_engine_query_counts_parts_and_feeds_the_placement_only_builder(oracle_ops, scene, smin, split):
+    """det6d_ball_query_pair_grid_lists + det6d_compact_groups_pair_counted (round 5): counts and the index slots the list
+    builder reads equal the oracle's query; the per-block part tables the query leaves in hdr equal a count over the oracle's
+    counts; the placement-only builder fed by them gives the lists of det6d_compact_groups_pair (count + place) word for word.
+    Light centres (a lane walks its candidates), heavy centres (dense blob / ray-cast near field: a wave each) and both kinds
+    inside one wave occur."""
+    from de6d_amd.ops import fused
+    from tests.util import beam_batch, make_batch
+    rng = np.random.default_rng(77)
+    b, n, m = 3, 16384, 1024
+    if scene == "uniform":
+        xyz = make_batch(910, b, n)[..., :3]
+    elif scene == "beam":
+        xyz = beam_batch(911, b, n)[..., :3]
+    elif scene == "dup":
+        xyz = make_batch(912, b, n, dup_frac=0.3)[..., :3]
+    else:
+        xyz = (rng.normal(size=(b, n, 3)) * [6.0, 6.0, 0.4]).astype(np.float32)
+        xyz[:, ::2] *= np.float32(8.0)                       # a dense core inside a sparse halo
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.choice(n, m, replace=False)] + np.float32(0.004))
+    new_xyz[:, 5] = 900.0                                    # empty balls
+    sa, sb = (0.0, 0.2, 16), (0.2, 0.8, 32)
+    old = fused.COMPACT_SMIN, fused.COMPACT_SPLIT
+    fused.COMPACT_SMIN, fused.COMPACT_SPLIT = smin, split
+    try:
+        got = fused.ball_query_pair_lists(dev(xyz), dev(new_xyz), sa, sb)
+        assert got is not None
+        ca, ia, cb, ib, la, lb = got
+        oca, oia = oracle_ops.ball_query_dilated(sa[0], sa[1], sa[2], xyz, new_xyz)
+        ocb, oib = oracle_ops.ball_query_dilated(sb[0], sb[1], sb[2], xyz, new_xyz)
+        for c, i, oc, oi, ns, lst in ((ca, ia, oca, oia, 16, la), (cb, ib, ocb, oib, 32, lb)):
+            c, i = c.cpu().numpy(), i.cpu().numpy()
+            np.testing.assert_array_equal(c, oc)
+            need = np.maximum(4, 2 ** np.ceil(np.log2(np.maximum(oc, 1))).astype(np.int64))
+            live = np.arange(ns)[None, None, :] < need[..., None]
+            np.testing.assert_array_equal(np.where(live, i, 0), np.where(live, oi, 0))
+            # the part tables: 7 ints per block of 256 centres
+            sm, sp = min(smin, ns), min(max(fused.COMPACT_SPLIT, min(smin, ns)), ns)
+            kk = np.clip(oc.reshape(-1), 1, ns)
+            pow2 = np.maximum(sm, 2 ** np.ceil(np.log2(kk)).astype(np.int64))
+            rows = np.where(kk > sp, (kk + sp - 1) // sp * sp, pow2)
+            table = lst.hdr.cpu().numpy()[16:16 + 7 * (b * m // 256)].reshape(-1, 7)
+            for cls in range(6):
+                np.testing.assert_array_equal(table[:, cls], ((rows & (32 >> cls)) != 0).reshape(-1, 256).sum(1))
+            np.testing.assert_array_equal(table[:, 6], np.minimum(oc, ns).reshape(-1, 256).sum(1))
+        if scene in ("beam", "blob"):
+            assert (ocb == 32).any()                         # capped balls: the wave-per-centre route with its pruning threshold
+        pooled = torch.full((b * m, 64), 7.0, device='cuda')
+        counted = fused.compact_groups_pair([(ca, ia), (cb, ib)], n, pooled, [(0, 32), (32, 32)], counted=(la, lb))
+        # reference lists: the padded query + the counting builder
+        fa, fia, fb, fib = fused.ball_query_pair(dev(xyz), dev(new_xyz), sa, sb, grid=True)
+        pooled2 = torch.full((b * m, 64), 7.0, device='cuda')
+        plain = fused.compact_groups_pair([(fa, fia), (fb, fib)], n, pooled2, [(0, 32), (32, 32)])
+        for x, y in zip(counted, plain):
+            hx, hy = x.hdr.cpu().numpy(), y.hdr.cpu().numpy()
+            np.testing.assert_array_equal(hx[:10], hy[:10])
+            live_rows = int(hx[0])
+            np.testing.assert_array_equal(x.crow_p.cpu().numpy()[:live_rows], y.crow_p.cpu().numpy()[:live_rows])
+            np.testing.assert_array_equal(x.crow_c.cpu().numpy()[:live_rows], y.crow_c.cpu().numpy()[:live_rows])
+        assert torch.equal(pooled, pooled2)
+    finally:
+        fused.COMPACT_SMIN, fused.COMPACT_SPLIT = old
