@@ -356,7 +356,8 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
     const int ns = sh == 0 ? ns_a : ns_b;
     const LT *Lw = reinterpret_cast<const LT *>(lane_lists_raw) + (sh == 0 ? 0 : (size_t)ns_a * kLaneThreads) + wave * 64;
     int *out = qa.idx[sh] + ((size_t)bs * m + blockIdx.x * kLaneThreads + wave * 64) * ns;
-    const int live = min(64, m - (blockIdx.x * kLaneThreads + wave * 64));      // centres of this wave that exist (may be <= 0)
+    const int live = min(64, m - ((int)blockIdx.x * kLaneThreads + wave * 64)); // centres of this wave that exist (may be <= 0; int, not
+                                                                                // blockIdx's unsigned: a negative count must stay negative)
     if ((ns & 3) == 0) {
       const int gper = ns >> 2;                    // 16-byte groups per centre
       const float rg = __builtin_amdgcn_rcpf((float)gper);

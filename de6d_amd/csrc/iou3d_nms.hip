@@ -15,6 +15,30 @@
 
 namespace {
 
+// ---- separated pairs ------------------------------------------------------------------------------------------------------
+// A suppression bit is `iou_bev(a, b) > thresh` (iou3d_nms_kernel.cu:267-311).  The rotated overlap behind it is ~3 000 vector
+// instructions per pair (16 edge tests, 8 corner tests, a bubble sort by atan2), and almost all pairs of a scene's candidates are
+// far apart.  Two boxes whose centres are farther apart than the sum of their CIRCUMRADII (plus a margin) cannot produce a set
+// bit in the reference's arithmetic:
+//   * no corner of one passes check_in_box2d of the other (iou3d_cpu.cpp:75-85: its 1e-2 margin grows a box by at most
+//     1.5e-2 in any direction; the radius below carries 5e-2 + 1e-4 relative + 1e-5 of the coordinates for that and rounding);
+//   * a segment pair contributes a point only if s1 * s2 > 0 && s3 * s4 > 0 (iou3d_cpu.cpp:87-103); for disjoint convex
+//     boxes that takes a rounding-flipped sign of a cross product of (near-)collinear edges, and a non-zero area needs THREE
+//     such points with finite coordinates — the collinear branch divides by D = a0 * b1 - a1 * b0 ~ 0, so what such pairs
+//     yield is inf / NaN corner sums, a NaN area and `NaN > thresh` == false, which is what skipping the pair gives too.
+// tests/test_nms_filter.py runs the reference's own iou3d_cpu.cpp over millions of separated pairs, rows of collinear
+// axis-aligned boxes included: no pair the rule skips has an IoU above 0 there.  The rule is used where only the BIT matters (mask
+// kernels), never in det6d_boxes_iou_bev / _overlap_bev, whose matrices are the reference's value for every pair.  thresh < 0
+// (nothing real) switches it off.
+__device__ __forceinline__ float d6_nms_radius(float x, float y, float dx, float dy) {
+  return 0.5f * sqrtf(dx * dx + dy * dy) * 1.0001f + 0.05f + 1e-5f * (fabsf(x) + fabsf(y));
+}
+// false only when the pair is provably separated (any NaN / inf leaves it true: the pair is evaluated in full)
+__device__ __forceinline__ bool d6_nms_near(float xa, float ya, float ra, float xb, float yb, float rb) {
+  const float ex = xa - xb, ey = ya - yb, s = ra + rb;
+  return !(ex * ex + ey * ey > s * s);
+}
+
 template <bool IOU>
 __global__ void boxes_pair_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
                                   const float *__restrict__ boxes_b, float *__restrict__ ans) {
@@ -47,7 +71,11 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thre
 #pragma unroll
   for (int c = 0; c < 7; ++c) bj[c] = j < boxes_num ? boxes[(size_t)j * 7 + c] : 0.f;
   bool sup = false;
-  if (j > i && j < boxes_num) {
+  // (separated pairs cannot set a bit: see d6_nms_near; the axis-aligned iou_normal is cheap and evaluated for every pair)
+  const bool live = j > i && j < boxes_num &&
+                    (NORMAL || thresh < 0.f ||
+                     d6_nms_near(bi[0], bi[1], d6_nms_radius(bi[0], bi[1], bi[3], bi[4]), bj[0], bj[1], d6_nms_radius(bj[0], bj[1], bj[3], bj[4])));
+  if (live) {
     const float v = NORMAL ? d6_iou_normal(bi, bj) : d6_iou_bev(bi, bj);
     sup = v > thresh;
   }
@@ -138,6 +166,7 @@ struct PostWs {          // layout of the workspace, per scene
   int order[kPostMaxP];
   float sorted[kPostMaxP * 8];                 // first 7 = box dims used by NMS
   unsigned long long mask[kPostMaxP * kPostCB];
+  float4 key[kPostMaxP];                       // (x, y, circumradius + margin, -) of the sorted boxes: the separated-pair test
 };
 
 __global__ __launch_bounds__(kPostThreads) void post_rank_kernel(int p, int ncls, const float *__restrict__ cls,
@@ -173,6 +202,8 @@ __global__ __launch_bounds__(kPostThreads) void post_rank_kernel(int p, int ncls
       ws.order[rank] = i;
 #pragma unroll
       for (int c = 0; c < 7; ++c) ws.sorted[rank * 8 + c] = boxes[(size_t)i * 9 + c];
+      const float bx = boxes[(size_t)i * 9 + 0], by = boxes[(size_t)i * 9 + 1];
+      ws.key[rank] = make_float4(bx, by, d6_nms_radius(bx, by, boxes[(size_t)i * 9 + 3], boxes[(size_t)i * 9 + 4]), 0.f);
       atomicAdd(&s_cand, 1);
     }
   }
@@ -180,28 +211,63 @@ __global__ __launch_bounds__(kPostThreads) void post_rank_kernel(int p, int ncls
   if (tid == 0) ws.cand = min(s_cand, pre_max);
 }
 
+// Suppression rows of kMaskRows consecutive sorted rows of one scene per workgroup, in two phases (round 5):
+//   A  every (row, column) pair of the chunk above the diagonal through the separated-pair test (6 vector instructions per 64
+//      pairs); the pairs that survive are appended to a queue in LDS (16-bit entries: local row | column);
+//   B  the queue is evaluated DENSELY — one rotated IoU per lane with all lanes live — and the set bits are OR-ed into the rows
+//      in LDS.
+// Round 4 evaluated every pair in place: on 65536-point scenes (1024 candidates, 524 k pairs per scene, 76 % of the pipeline's
+// workgroup-time) a wave ran the 3 000-instruction overlap for 64 pairs of which a handful were near each other.
+constexpr int kMaskRows = 8;
+
 __global__ __launch_bounds__(256) void post_mask_kernel(float nms_thr, PostWs *__restrict__ ws_all) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  PostWs &ws = ws_all[blockIdx.z];
+  __shared__ unsigned short queue[kMaskRows * kPostMaxP];
+  __shared__ unsigned int rows_s[kMaskRows][2 * kPostCB];
+  __shared__ float4 rkey[kMaskRows];
+  __shared__ int q_count;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  PostWs &ws = ws_all[blockIdx.y];
   const int cand = ws.cand;
-  const int i = blockIdx.x * 4 + wave;        // sorted row
-  const int col_start = blockIdx.y;
-  if (i >= cand) return;
-  const int row_start = i >> 6;
-  if (col_start < row_start || col_start * 64 >= cand) return;
-  const int col_size = min(cand - col_start * 64, 64);
-  const int j = col_start * 64 + lane;
-  float bi[7], bj[7];
-#pragma unroll
-  for (int c = 0; c < 7; ++c) {
-    bi[c] = ws.sorted[i * 8 + c];
-    bj[c] = lane < col_size ? ws.sorted[j * 8 + c] : 0.f;
+  const int r0 = blockIdx.x * kMaskRows;
+  if (r0 >= cand) return;
+  const int nrow = min(kMaskRows, cand - r0);
+  const int cb0 = r0 >> 6, cb1 = (cand + 63) >> 6;                 // live column blocks of this chunk
+  if (tid == 0) q_count = 0;
+  if (tid < kMaskRows) rkey[tid] = ws.key[min(r0 + tid, cand - 1)];
+  for (int e = tid; e < kMaskRows * 2 * kPostCB; e += 256) (&rows_s[0][0])[e] = 0u;
+  __syncthreads();
+  const bool filter = nms_thr >= 0.f;
+  // ---- A
+  for (int c = cb0 + wave; c < cb1; c += 4) {
+    const int j = c * 64 + lane;
+    const float4 kj = ws.key[min(j, cand - 1)];
+    for (int r = 0; r < nrow; ++r) {
+      const float4 ki = rkey[r];
+      const bool near = j > r0 + r && j < cand && (!filter || d6_nms_near(ki.x, ki.y, ki.z, kj.x, kj.y, kj.z));
+      const unsigned long long m = __ballot(near);
+      if (m != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&q_count, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (near) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((r << 10) | j);
+      }
+    }
   }
-  const int start = (row_start == col_start) ? (i & 63) + 1 : 0;
-  bool sup = false;
-  if (lane >= start && lane < col_size) sup = d6_iou_bev(bi, bj) > nms_thr;
-  const unsigned long long word = __ballot(sup);
-  if (lane == 0) ws.mask[i * kPostCB + col_start] = word;
+  __syncthreads();
+  // ---- B
+  const int total = q_count;
+  for (int q = tid; q < total; q += 256) {
+    const int e = queue[q], r = e >> 10, j = e & 1023;
+    float bi[7], bj[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { bi[c] = ws.sorted[(r0 + r) * 8 + c]; bj[c] = ws.sorted[j * 8 + c]; }
+    if (d6_iou_bev(bi, bj) > nms_thr) atomicOr(&rows_s[r][j >> 5], 1u << (j & 31));
+  }
+  __syncthreads();
+  for (int e = tid; e < nrow * (cb1 - cb0); e += 256) {
+    const int r = e / (cb1 - cb0), c = cb0 + e % (cb1 - cb0);
+    ws.mask[(r0 + r) * kPostCB + c] = (unsigned long long)rows_s[r][2 * c] | ((unsigned long long)rows_s[r][2 * c + 1] << 32);
+  }
 }
 
 __global__ __launch_bounds__(64) void post_select_kernel(int p, const float *__restrict__ boxes, int post_max,
@@ -331,7 +397,7 @@ DET6D_API int det6d_postprocess(int b, int p, int ncls, const float *cls, const 
   PostWs *ws = (PostWs *)workspace;
   hipLaunchKernelGGL(post_rank_kernel, dim3(b), dim3(kPostThreads), 0, s, p, ncls, cls, boxes, score_thr,
                      pre_max > kPostMaxP ? kPostMaxP : pre_max, ws);
-  hipLaunchKernelGGL(post_mask_kernel, dim3(det6d_divup(p, 4), det6d_divup(p, 64), b), dim3(256), 0, s, nms_thr, ws);
+  hipLaunchKernelGGL(post_mask_kernel, dim3(det6d_divup(p, kMaskRows), b), dim3(256), 0, s, nms_thr, ws);
   const size_t lds = (size_t)p * ((p + 63) / 64) * sizeof(unsigned long long);
   static bool big_lds_enabled = false;
   if (lds > 48 * 1024 && !big_lds_enabled) {   // one-time opt-in for > 64 KB of dynamic LDS (160 KB per CU on gfx950)

@@ -273,6 +273,39 @@ def test_postprocess_bit_exact(ext, oracle_ops, p, ncls):
     assert ref[4][1] == 0 and ref[4][0] > 0
 
 
+@pytest.mark.parametrize("p,kind", [(1024, "clusters"), (1024, "rows"), (1000, "dense"), (640, "clusters"), (8, "rows"), (1, "dense")])
+def test_postprocess_pair_filtered_mask_at_1024_candidates(ext, oracle_ops, p, kind):
+    """the two-phase suppression-mask kernel (separated pairs skipped, the rest evaluated from a dense queue: csrc/iou3d_nms.hip)
+    at the candidate counts of BASELINE config 5 (1024 per scene) against the oracle, which evaluates EVERY pair: vote-like
+    clusters (many near pairs per row), rows of collinear equal boxes (the rule's worst case), one dense blob (nothing skipped:
+    the queue holds every pair of a chunk), no score filter so that all p candidates reach the NMS"""
+    fused = ext[2]
+    b = 3
+    rng = np.random.default_rng(p * 7 + len(kind))
+    boxes = np.zeros((b * p, 9), np.float32)
+    boxes[:, :7] = random_boxes(3, b * p, spread=60.0)
+    if kind == "clusters":
+        centres = rng.uniform(-50, 50, (40, 2))
+        pick = rng.integers(0, 40, b * p)
+        boxes[:, 0] = centres[pick, 0] + rng.normal(size=b * p) * 0.7
+        boxes[:, 1] = centres[pick, 1] + rng.normal(size=b * p) * 0.7
+    elif kind == "rows":
+        boxes[:, 3], boxes[:, 4], boxes[:, 6] = 3.9, 1.6, 0.0
+        boxes[:, 0] = (np.arange(b * p) % 97) * 1.3
+        boxes[:, 1] = ((np.arange(b * p) // 97) % 5) * 1.55
+    else:
+        boxes[:, 0] = rng.normal(size=b * p) * 2.0
+        boxes[:, 1] = rng.normal(size=b * p) * 2.0
+    boxes[:, 7] = rng.normal(size=b * p) * 0.1
+    cls = (rng.normal(size=(b * p, 1)) * 2 + 1).astype(np.float32)
+    for thr in (0.01, 0.3):
+        got = fused.postprocess(dev(cls), dev(boxes), b, 0.0, 4096, 100, thr)
+        ref = oracle_ops.postprocess(cls, boxes, b, 0.0, 4096, 100, thr)
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g.cpu().numpy(), r)
+    assert ref[4].min() > 0
+
+
 @pytest.mark.parametrize("n,m,sa,sb", [(16384, 700, (0.0, 0.2, 16), (0.2, 0.8, 32)), (4096, 1024, (0.0, 0.8, 16), (0.8, 1.6, 32)),
                                        (512, 256, (0.0, 4.8, 16), (0.0, 6.4, 32)), (100, 7, (0.0, 0.01, 8), (0.0, 50.0, 128)),
                                        (1000, 33, (1.0, 3.0, 5), (0.5, 2.0, 70))])
