@@ -165,7 +165,7 @@ __device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restr
 // hold ~20 candidates; the round-2..4 kernel gave every centre a whole wave (three 64-lane sweeps with ~6 live lanes each,
 // two ballots, two list rankings: ~275 vector instructions per centre, 49 M per 32-scene pass — the largest vector-ALU
 // consumer beside the fp32 MFMAs it shares the issue port with).  Now
-//   LIGHT centres (<= kLightCap candidates): the lane walks its own candidates one by one and keeps its hits SORTED in a
+//   LIGHT centres (few candidates; the cut is chosen per wave, see the kernel): the lane walks its own candidates one by one and keeps its hits SORTED in a
 //     per-lane LDS list (insertion from the back: candidates of a cell arrive nearly in index order);
 //   HEAVY centres (dense parts of a real sweep: hundreds of candidates): the wave takes them one at a time, lane =
 //     candidate, exactly as before (running selection in a kListCap-entry list, pruning threshold, ranked at the end);
@@ -175,7 +175,7 @@ __device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restr
 //     saves that builder's counting launch.
 constexpr int kListCap = 128;
 constexpr int kLaneThreads = 256;
-constexpr int kLightCap = 48;
+constexpr int kLightCap = 192;               // most candidates a lane walks by itself (experiments build: DET6D_BQ_LIGHT_CAP)
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -231,16 +231,17 @@ __device__ __forceinline__ void wave_centre_scan(float qx, float qy, float qz, c
 }
 
 // a lane's sorted list lives at L[i * kLaneThreads] (i = 0 .. ns - 1; the caller has added its thread index): every lane of a
-// wave touches its own bank whatever its i.  `last` = the largest kept entry once the list is full.
+// wave touches its own bank whatever its i.  `last` = the largest kept entry (-1: none yet), held in a register: the candidates
+// of a cell row arrive nearly in index order, so the common hit is an APPEND — one LDS store, no LDS read on the walk's
+// dependency chain; a hit that belongs inside the list shifts the larger entries up.
 template <typename LT>
 __device__ __forceinline__ void lane_insert(LT *__restrict__ L, int &cnt, int &last, int ns, int k) {
-  int pos;
-  if (cnt == ns) {
-    if (k > last) return;                          // not among the ns smallest
-    pos = ns - 1;                                  // replaces the largest
-  } else {
-    pos = cnt++;
+  if (k > last) {
+    if (cnt < ns) { L[cnt * kLaneThreads] = (LT)k; ++cnt; last = k; }     // (full: not among the ns smallest)
+    return;
   }
+  const bool full = cnt == ns;
+  int pos = full ? ns - 1 : cnt++;                  // the slot that opens at the end (full: the largest entry falls out)
   while (pos > 0) {
     const int v = (int)L[(pos - 1) * kLaneThreads];
     if (v < k) break;
@@ -248,7 +249,7 @@ __device__ __forceinline__ void lane_insert(LT *__restrict__ L, int &cnt, int &l
     --pos;
   }
   L[pos * kLaneThreads] = (LT)k;
-  if (cnt == ns) last = (int)L[(ns - 1) * kLaneThreads];
+  if (full) last = (int)L[(ns - 1) * kLaneThreads];
 }
 
 struct QueryArgs {
@@ -263,6 +264,7 @@ struct QueryArgs {
   const float4 *sorted_pts;
   int *cnt[2], *idx[2];
   CompactCountArgs count[2];
+  int light_cap;
 };
 
 // l mod c for 0 <= l < 4096, 1 <= c <= 64 (rc ~ 1 / c): the quotient estimate is exact or one short
@@ -303,24 +305,48 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
     }
   }
   const int n0 = end[0] - beg[0], n01 = n0 + end[1] - beg[1], cand = n01 + end[2] - beg[2];
-  const bool heavy = cand > kLightCap;
-  const int walk = heavy ? 0 : cand;
-  int ca = 0, cb = 0, last_a = 0x7fffffff, last_b = 0x7fffffff;
-
-  // ---- light centres: lane = centre, one candidate per step, the next one's record already in flight
+  // Light or heavy, decided per WAVE: a wave walks its light lanes in lockstep, so the walk costs the wave max(cand of its
+  // light lanes) steps of ~40 vector instructions whatever the other lanes hold, and a heavy centre ~300 for the wave.  The
+  // cut T that minimises  40 T + 300 #(cand > T)  over a few candidates (six ballots, scalar arithmetic) keeps a sparse wave
+  // from following one dense centre through 200 steps, and lets a uniformly dense wave (65536-point scenes: ~70 candidates
+  // per centre) walk instead of taking 64 turns.
+  int cut = 0;
   {
+    int best_cost = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      constexpr int kCuts[7] = {16, 32, 48, 64, 96, 128, 192};
+      const int T = kCuts[t];
+      if (T > qa.light_cap && t > 0) break;
+      const int cost = 40 * T + 300 * (int)__popcll(__ballot(cand > T));
+      if (cost < best_cost) { best_cost = cost; cut = T; }
+    }
+  }
+  const bool heavy = cand > cut;
+  const int walk = heavy ? 0 : cand;
+  int ca = 0, cb = 0, last_a = -1, last_b = -1;
+
+  // ---- light centres: lane = centre, kWalk candidates per step (their records are fetched together: the walk is a chain of
+  // L2 round trips, not of arithmetic)
+  {
+    constexpr int kWalk = 4;
     const float rin2_a = qa.rin2_a, rout2_a = qa.rout2_a, rin2_b = qa.rin2_b, rout2_b = qa.rout2_b;
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (0 < walk) nxt = si[0 < n0 ? beg[0] : (0 < n01 ? beg[1] - n0 : beg[2] - n01)];
-    for (int j = 0; __ballot(j < walk) != 0ull; ++j) {
-      const float4 c = nxt;
-      const int j1 = j + 1;
-      if (j1 < walk) nxt = si[j1 < n0 ? beg[0] + j1 : (j1 < n01 ? beg[1] + (j1 - n0) : beg[2] + (j1 - n01))];
-      if (j < walk) {
-        const int k = __float_as_int(c.w);
-        const float d2 = d6_sqdist(qx - c.x, qy - c.y, qz - c.z);
-        if (d2 >= rin2_a && d2 < rout2_a) lane_insert<LT>(LA, ca, last_a, ns_a, k);
-        if (d2 >= rin2_b && d2 < rout2_b) lane_insert<LT>(LB, cb, last_b, ns_b, k);
+    for (int j0 = 0; __ballot(j0 < walk) != 0ull; j0 += kWalk) {
+      float4 c[kWalk];
+#pragma unroll
+      for (int u = 0; u < kWalk; ++u) {
+        const int j = j0 + u;
+        c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < walk) c[u] = si[j < n0 ? beg[0] + j : (j < n01 ? beg[1] + (j - n0) : beg[2] + (j - n01))];
+      }
+#pragma unroll
+      for (int u = 0; u < kWalk; ++u) {
+        if (j0 + u < walk) {
+          const int k = __float_as_int(c[u].w);
+          const float d2 = d6_sqdist(qx - c[u].x, qy - c[u].y, qz - c[u].z);
+          if (d2 >= rin2_a && d2 < rout2_a) lane_insert<LT>(LA, ca, last_a, ns_a, k);
+          if (d2 >= rin2_b && d2 < rout2_b) lane_insert<LT>(LB, cb, last_b, ns_b, k);
+        }
       }
     }
   }
@@ -457,6 +483,8 @@ static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int
   qa.new_xyz = new_xyz; qa.hdr = hdr; qa.cell_start = cell_start; qa.sorted_pts = sorted_pts;
   qa.cnt[0] = cnt_a; qa.cnt[1] = cnt_b; qa.idx[0] = idx_a; qa.idx[1] = idx_b;
   for (int g = 0; g < 2; ++g) qa.count[g] = count ? count[g] : CompactCountArgs{0, 0, 0, nullptr};
+  static const int light_cap = det6d_env_int("DET6D_BQ_LIGHT_CAP", kLightCap);
+  qa.light_cap = light_cap < 0 ? 0 : light_cap;
   // index rows leave as 16-byte stores when nsample is a multiple of 4 (idx rows are then 16-byte aligned like their buffers)
   if (((ns_a & 3) == 0 && ((uintptr_t)idx_a & 15)) || ((ns_b & 3) == 0 && ((uintptr_t)idx_b & 15))) return DET6D_EINVAL;
   const bool narrow = n <= 65536;                  // point indices fit 16 bits: half the LDS per workgroup
@@ -499,6 +527,8 @@ DET6D_API int det6d_ball_query_pair_grid_lists(int b, int n, int m, float rin_a,
   if (b == 0 || m == 0) return DET6D_OK;
   int sa = split, sb = split;
   const int smin_a = smin < ns_a ? smin : ns_a, smin_b = smin < ns_b ? smin : ns_b;
+  if (sa && sa < smin_a) sa = smin_a;              // (as det6d_compact_groups_pair does)
+  if (sb && sb < smin_b) sb = smin_b;
   if (det6d_compact_check_group(ns_a, smin_a, &sa) || det6d_compact_check_group(ns_b, smin_b, &sb)) return DET6D_EINVAL;
   const CompactCountArgs count[2] = {{ns_a, smin_a, det6d_compact_split_tol(sa), hdr_a + 16},
                                      {ns_b, smin_b, det6d_compact_split_tol(sb), hdr_b + 16}};

@@ -196,12 +196,24 @@ __device__ __forceinline__ void pick_slot(int ws, int wl, const float (&px)[N], 
 // but the per-round reduction/broadcast code (which every wave executes) runs on 8, 4 or 1 waves
 // instead of 16, and a single-wave block (N <= 1024) needs no LDS and no barrier at all.
 // Distances are evaluated two points at a time with packed fp32 ops (v_pk_add/mul/fma_f32).
-template <int LOG2T, int SLOTS, bool WEIGHTED>
+//
+// S-FPS score (sampling_gpu.cu:466): float(double(t) * max(double(w), 1e-12)).  While w >= 1e-12 the product of the two floats
+// is EXACT in double (48 significand bits), so rounding it to float once IS the IEEE fp32 product t * w (fp32 denormals are
+// kept in this build: .amdhsa_float_denorm_mode_32 3): FASTW scores a point with one v_mul_f32 instead of convert / fp64
+// multiply / convert and holds the weights as 32-bit values (SLOTS fewer registers).  A scene that holds a weight below
+// 1e-12 — or a NaN weight, which the reference's max() turns into 1e-12 — cannot take that form: the FASTW launch writes
+// flags[scene] = 1 for it and returns, and the exact-double launch behind it (GUARDED: it returns at once for every scene
+// whose flag is 0) samples that scene.  Two kernels rather than two paths in one: with both paths inlined the allocator sizes
+// the kernel for their union (fat<9, 32>: 202 -> 256 registers + 464 bytes of scratch per lane).
+template <int LOG2T, int SLOTS, bool WEIGHTED, bool FASTW = false>
 __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int log2s, int log2pptv,
                                                              const float *__restrict__ xyz,
                                                              const float *__restrict__ weights,
                                                              float *__restrict__ temp,
-                                                             int *__restrict__ idxs, const FpsView vw) {
+                                                             int *__restrict__ idxs, const FpsView vw,
+                                                             int *__restrict__ flags = nullptr) {
+  static_assert(WEIGHTED || !FASTW, "FASTW is a form of the weighted sampler");
+  if (WEIGHTED && !FASTW && flags != nullptr && flags[(size_t)blockIdx.x * vw.temp_bstride] == 0) return;   // GUARDED
   static_assert(SLOTS >= 2 && SLOTS % 2 == 0, "pairs");
   constexpr int T = 1 << LOG2T;
   constexpr int NW = T / 64;
@@ -226,8 +238,9 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
 
   float px[SLOTS], py[SLOTS], pz[SLOTS];   // statically indexed only -> plain VGPRs
   float pt[SLOTS];
-  double pw[SLOTS];
+  double pw[FASTW ? 1 : SLOTS];
   float pwf[SLOTS];
+  bool small = false;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int k = slot_point(s);
@@ -241,8 +254,14 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
     if (WEIGHTED) {
       pwf[s] = weights[k];
       if (vw.w_is_score) pwf[s] = d6_sigmoid_powf(pwf[s], vw.gamma);
-      pw[s] = fmax((double)pwf[s], 1e-12);   // `max(weights[k], 1e-12)` in double, sampling_gpu.cu:466
+      if (FASTW) small = small || !((double)pwf[s] >= 1e-12);
+      else pw[s] = fmax((double)pwf[s], 1e-12);   // `max(weights[k], 1e-12)` in double, sampling_gpu.cu:466
     }
+  }
+  if (FASTW) {
+    small = NW > 1 ? (__syncthreads_or(small ? 1 : 0) != 0) : (__ballot(small) != 0ull);
+    if (h == 0) flags[(size_t)blockIdx.x * vw.temp_bstride] = small ? 1 : 0;
+    if (small) return;                          // this scene is sampled by the exact-double launch behind this one
   }
 
   float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
           const float t = d6_vmin(d[e], pt[s]);
           pt[s] = t;
           float score = t;
-          if (WEIGHTED) score = (float)((double)t * pw[s]);
+          if (WEIGHTED) score = FASTW ? t * pwf[s] : (float)((double)t * pw[s]);
           const bool up = score > best;
           bs = up ? s : bs;
           best = up ? score : best;
@@ -406,6 +425,12 @@ int opt_n_threads_log2(int work_size) {
   return pow_2;
 }
 
+// experiments build: DET6D_FPS_NO_FASTW=1 keeps the exact-double S-FPS launch only (A/B)
+static bool no_fastw() {
+  static const bool off = det6d_env_int("DET6D_FPS_NO_FASTW", 0) != 0;
+  return off;
+}
+
 template <bool W>
 int launch_fps(int b, int n, int m, const float *xyz, const float *weights, float *temp, int *idx,
                const FpsView &vw, hipStream_t stream) {
@@ -418,13 +443,19 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
   const int ppt = (n + S - 1) / S;
   dim3 grid(b), block(threads);
   // fat-thread kernels: N = SLOTS << LOG2T exactly, T <= S
+  // S-FPS with a free workspace (det6d_fps_fused: the min-distances start at 1e10 implicitly, `temp` is scratch): the fp32
+  // scoring launch, then the exact-double launch for the scenes it handed over (flag word = first word of the scene's scratch)
+  int *flags = (W && vw.init_temp && temp && !no_fastw()) ? reinterpret_cast<int *>(temp) : nullptr;
 #define FPS_FAT(LT, SL)                                                                        \
   do {                                                                                         \
     int lp = 0;                                                                                \
     while ((1 << lp) < ppt) ++lp;                                                              \
     static const unsigned hog = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W>, 1024);        \
+    if (flags)                                                                                 \
+      hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
+                         lp, xyz, weights, temp, idx, vw, flags);                              \
     hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
-                       lp, xyz, weights, temp, idx, vw);                                       \
+                       lp, xyz, weights, temp, idx, vw, flags);                                \
     return det6d_check_launch("det6d_fps");                                                    \
   } while (0)
   if (n == S * ppt && (ppt & (ppt - 1)) == 0) {

@@ -21,9 +21,25 @@
 #include "common.h"
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
-
 namespace {
+
+// exclusive prefix sum over the 1024 threads of a workgroup: wave scan (six shuffles), the sixteen wave totals through LDS
+// (`wtot`: 16 words; free again when the call returns).  (Rounds 2-4 used hipcub::BlockScan here.)
+__device__ __forceinline__ unsigned block_exclusive_sum_1024(unsigned v, unsigned *__restrict__ wtot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  unsigned base = 0u;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  __syncthreads();
+  return base + incl - v;
+}
 
 __device__ __forceinline__ unsigned bitrev_bits(unsigned v, int bits) {
   return bits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));
@@ -52,9 +68,12 @@ __device__ __forceinline__ int min_key_lane(unsigned long long cand, int k, int 
 // Pre-pass: spatial order of a scene.  perm[b, p] = original index of the point at sorted position p.
 // Any permutation is CORRECT for the samplers below; the order only makes their regions compact.
 // ------------------------------------------------------------------------------------------------
+// src != nullptr (the cooperative 32768 / 65536-point sampler, fps_coop.hip): workgroup g orders the N points src[g N ..] of
+// scene g / parts (one spatial PART of that scene, split off by coop_split_kernel) instead of a whole N-point scene.
 template <int IPT>
 __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long long xyz_bstride, const float *__restrict__ xyz,
-                                                         int *__restrict__ perm) {
+                                                         int *__restrict__ perm, const int *__restrict__ src = nullptr,
+                                                         int parts = 1) {
   // A 4 x 4 k-d grid of equal counts: order by x, cut into 4 strips, order every strip by y, cut into 4: region g = sorted
   // positions [g n/16, (g+1) n/16).  A wave of the samplers owns one region, and its bounding box is a tight rectangle: a new
   // sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into 16 equal runs gives 2.65: a
@@ -65,19 +84,19 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   // sq_hide_lane_duplicates find most of them in one lane.  (Rounds 2-4 ran two block radix sorts here: 124 us for 16384 points.)
   constexpr int N = 1024 * IPT;
   constexpr int BY = N / 4;                    // y bins per strip: one point per bin on average
-  typedef hipcub::BlockScan<unsigned, 1024> Scan;
-  __shared__ typename Scan::TempStorage scan_tmp;
+  __shared__ unsigned scan_tmp[16];
   __shared__ unsigned bins[N];                 // histogram, then running offsets (x pass: the first 1024)
   __shared__ int sorted[N];
   __shared__ float red[4][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  xyz += (size_t)blockIdx.x * xyz_bstride;
+  xyz += (size_t)(blockIdx.x / parts) * xyz_bstride;
   perm += (size_t)blockIdx.x * n;
+  if (src) src += (size_t)blockIdx.x * n;
   float x[IPT], y[IPT];
   float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
-    const int k = i * 1024 + tid;              // (coalesced: the point a thread holds does not matter here)
+    const int k = src ? src[i * 1024 + tid] : i * 1024 + tid;   // (coalesced: the point a thread holds does not matter here)
     x[i] = xyz[(size_t)k * 3 + 0];
     y[i] = xyz[(size_t)k * 3 + 1];
     if (x[i] == x[i] && fabsf(x[i]) < 1e30f) { xmin = fminf(xmin, x[i]); xmax = fmaxf(xmax, x[i]); }
@@ -105,9 +124,7 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   }
   __syncthreads();
   {
-    unsigned off;
-    Scan(scan_tmp).ExclusiveSum(bins[tid], off);
-    __syncthreads();
+    const unsigned off = block_exclusive_sum_1024(bins[tid], scan_tmp);     // (returns behind a barrier: every bins[tid] read)
     bins[tid] = off;
   }
   __syncthreads();
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
     unsigned cnt[IPT], total = 0u, base;
 #pragma unroll
     for (int i = 0; i < IPT; ++i) { cnt[i] = bins[tid * IPT + i]; total += cnt[i]; }
-    Scan(scan_tmp).ExclusiveSum(total, base);
+    base = block_exclusive_sum_1024(total, scan_tmp);
 #pragma unroll
     for (int i = 0; i < IPT; ++i) { bins[tid * IPT + i] = base; base += cnt[i]; }   // (every thread rewrites only its own bins)
   }
@@ -143,7 +160,11 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   unsigned key[IPT];
   int val[IPT];
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) { val[i] = sorted[tid * IPT + i]; key[i] = tie_key(val[i], log2s); }
+  for (int i = 0; i < IPT; ++i) {
+    val[i] = sorted[tid * IPT + i];
+    if (src) val[i] = src[val[i]];             // position inside the part -> point of the scene
+    key[i] = tie_key(val[i], log2s);
+  }
 #pragma unroll
   for (int i = 1; i < IPT; ++i) {
 #pragma unroll
@@ -340,6 +361,14 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, 
                          const float *xyz, const int *perm, int *idx, hipStream_t stream);
 
 // Called by fps.hip's launcher for D-FPS of 16384- and 4096-point scenes with fresh min-distances.  `perm` is (B, n) int32 scratch.
+// k-d order (4 x 4 cells of equal counts, lanes ordered by the tie key) of every 16384-point part src[g] of `subscenes`
+// scene parts (fps_coop.hip); perm[g] = the part's points in that order
+int det6d_fps_cell_sort_parts(int subscenes, int parts, int log2s, long long xyz_bstride, const float *xyz, const int *src, int *perm,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL((cell_sort_kernel<16>), dim3(subscenes), dim3(1024), 0, stream, 16384, log2s, xyz_bstride, xyz, perm, src, parts);
+  return det6d_check_launch("det6d_fps (cooperative: k-d order of the parts)");
+}
+
 int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                            const float *xyz, int *perm, int *idx, hipStream_t stream) {
   if (n != 16384 && n != 4096) return DET6D_EINVAL;

@@ -5,9 +5,10 @@
 //
 // The memory-resident fallback (fps.hip: fps_mem_kernel) re-reads all N points from L2 every pick: 111 us per pick on MI355X,
 // 1.8 s for the 16383 picks of a 65536-point scene.  Here a scene is held IN REGISTERS by PARTS = N / 16384 cooperating
-// workgroups (one per CU): the scene is sorted along a Morton curve (device radix sort over all scenes of the launch, key =
-// scene | 20-bit Morton code), part q keeps sorted positions [q * 16384, (q+1) * 16384) as 16 waves x 16 points per lane, one
-// bounding box per wave, exact floating-point skip test, explicit tie paths — the wave-skip sampler of fps_cells.hip.
+// workgroups (one per CU): the scene is cut into PARTS spatial parts of 16384 points (coop_split_kernel: counting partitions by
+// x and y), every part is put into the 4 x 4 k-d order of the single-workgroup sampler (fps_cells.hip: cell_sort_kernel), and
+// part q keeps its 16384 points as 16 waves x 16 points per lane, one bounding box per wave, exact floating-point skip test,
+// explicit tie paths — the wave-skip sampler of fps_cells.hip.
 //
 // Shipped form: MULTI-PICK rounds (fps_coop_multi_kernel; decision rule and its executable model: fps_seq.hip,
 // tests/models/fps_lookahead.py).  Per round every wave applies the round's picks to its points and republishes its top 4
@@ -31,8 +32,6 @@
 // workspace, completes the scene's picks with a valid index and leaves: det6d_fps_fused_status reports the launch as failed
 // instead of the GPU hanging.
 #include "fps_multi.h"
-
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -62,22 +61,42 @@ __device__ __forceinline__ int co_min_key_lane(unsigned long long cand, int k, i
   }
   return __builtin_ctzll(__ballot(mine && key == m));
 }
-__device__ __forceinline__ unsigned co_part1by1(unsigned v) {
-  v &= 0xFFFFu;
-  v = (v | (v << 8)) & 0x00FF00FFu;
-  v = (v | (v << 4)) & 0x0F0F0F0Fu;
-  v = (v | (v << 2)) & 0x33333333u;
-  v = (v | (v << 1)) & 0x55555555u;
-  return v;
+// ---- pre-pass 1: the scene cut into PARTS spatial parts of exactly 16384 points (PARTS = 4: two halves by x, each cut in two
+// by y; PARTS = 2: two halves by x); clears the exchange area.  Counting partition in LDS: a histogram over 4096 bins of the
+// coordinate, an exclusive scan, one returning atomic per point for its position; the position decides the half — exact equal
+// counts whatever the distribution, the order inside a bin is whatever the atomics make it (any partition into equal parts
+// is CORRECT for the sampler; compact parts make its bounding boxes tight).  part_idx[scene][part][0 .. 16383] = the part's
+// points, which cell_sort_kernel<16> (fps_cells.hip) then puts into the 4 x 4 k-d order of the single-workgroup sampler.
+// (Rounds 2-4: 20-bit Morton keys + hipcub::DeviceRadixSort over all scenes + a lane-ordering kernel: 8 launches.)
+constexpr int kSplitBins = 4096;
+
+__device__ __forceinline__ unsigned co_block_exclusive_sum(unsigned v, unsigned *__restrict__ wtot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  unsigned base = 0u;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  __syncthreads();
+  return base + incl - v;
 }
 
-// ---- pre-pass 1: per-scene (x, y) extent -> 20-bit Morton keys, scene index in the bits above; clears the exchange area
-__global__ __launch_bounds__(1024) void coop_keys_kernel(int n, long long xyz_bstride, const float *__restrict__ xyz,
-                                                         unsigned *__restrict__ keys, unsigned *__restrict__ vals,
-                                                         unsigned long long *__restrict__ exch, int exch_words, int *err) {
+template <int PARTS>
+__global__ __launch_bounds__(1024) void coop_split_kernel(int n, long long xyz_bstride, const float *__restrict__ xyz,
+                                                          int *__restrict__ part_idx, unsigned long long *__restrict__ exch,
+                                                          int exch_words) {
+  constexpr int IPT = PARTS * kPartPoints / 1024;      // points per thread
   __shared__ float red[4][16];
+  __shared__ unsigned wtot[16];
+  __shared__ unsigned bins[2 * kSplitBins];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, scene = blockIdx.x;
   const float *p = xyz + (size_t)scene * xyz_bstride;
+  part_idx += (size_t)scene * n;
   float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
   for (int k = tid; k < n; k += 1024) {
     const float x = p[(size_t)k * 3], y = p[(size_t)k * 3 + 1];
@@ -86,41 +105,68 @@ __global__ __launch_bounds__(1024) void coop_keys_kernel(int n, long long xyz_bs
   }
   xmin = d6_wave_min(xmin); xmax = d6_wave_max(xmax); ymin = d6_wave_min(ymin); ymax = d6_wave_max(ymax);
   if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = ymin; red[3][wave] = ymax; }
+  for (int c = tid; c < 2 * kSplitBins; c += 1024) bins[c] = 0u;
   __syncthreads();
   xmin = red[0][0]; xmax = red[1][0]; ymin = red[2][0]; ymax = red[3][0];
   for (int w = 1; w < 16; ++w) {
     xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
     ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
   }
-  const float sx = xmax > xmin ? 1023.0f / (xmax - xmin) : 0.f;
-  const float sy = ymax > ymin ? 1023.0f / (ymax - ymin) : 0.f;
-  for (int k = tid; k < n; k += 1024) {
-    float fx = (p[(size_t)k * 3] - xmin) * sx, fy = (p[(size_t)k * 3 + 1] - ymin) * sy;
-    fx = fx == fx ? fminf(fmaxf(fx, 0.f), 1023.f) : 0.f;
-    fy = fy == fy ? fminf(fmaxf(fy, 0.f), 1023.f) : 0.f;
-    keys[(size_t)scene * n + k] = ((unsigned)scene << 20) | (co_part1by1((unsigned)fx) << 1) | co_part1by1((unsigned)fy);
-    vals[(size_t)scene * n + k] = (unsigned)k;
+  const float sx = xmax > xmin ? (float)(kSplitBins - 1) / (xmax - xmin) : 0.f;
+  const float sy = ymax > ymin ? (float)(kSplitBins - 1) / (ymax - ymin) : 0.f;
+  auto bin_of = [](float v, float lo, float scale) {
+    float f = (v - lo) * scale;
+    f = f == f ? fminf(fmaxf(f, 0.f), (float)(kSplitBins - 1)) : 0.f;
+    return (unsigned)f;
+  };
+  // ---- x: position of every point in x order -> half
+  for (int i = 0; i < IPT; ++i) atomicAdd(&bins[bin_of(p[(size_t)(i * 1024 + tid) * 3], xmin, sx)], 1u);
+  __syncthreads();
+  {
+    unsigned c[4], total = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c[q] = bins[tid * 4 + q]; total += c[q]; }
+    unsigned base = co_block_exclusive_sum(total, wtot);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { bins[tid * 4 + q] = base; base += c[q]; }
+  }
+  __syncthreads();
+  unsigned long long upper = 0ull;                     // bit i: point i of this thread lies in the upper half by x
+  for (int i = 0; i < IPT; ++i) {
+    const int k = i * 1024 + tid;
+    const unsigned pos = atomicAdd(&bins[bin_of(p[(size_t)k * 3], xmin, sx)], 1u);    // 0 .. n - 1, each once
+    if (PARTS == 2) part_idx[pos] = k;                 // part = pos / 16384, slot = pos % 16384
+    else if (pos >= (unsigned)(n / 2)) upper |= 1ull << i;
+  }
+  if (PARTS == 4) {
+    // ---- y inside the halves: bins [half][4096]; a half holds n / 2 points exactly, so its positions start at half * n / 2
+    __syncthreads();
+    for (int c = tid; c < 2 * kSplitBins; c += 1024) bins[c] = 0u;
+    __syncthreads();
+    for (int i = 0; i < IPT; ++i) {
+      const unsigned half = (unsigned)((upper >> i) & 1ull);
+      atomicAdd(&bins[half * kSplitBins + bin_of(p[(size_t)(i * 1024 + tid) * 3 + 1], ymin, sy)], 1u);
+    }
+    __syncthreads();
+    {
+      unsigned c[8], total = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { c[q] = bins[tid * 8 + q]; total += c[q]; }
+      unsigned base = co_block_exclusive_sum(total, wtot);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { bins[tid * 8 + q] = base; base += c[q]; }
+    }
+    __syncthreads();
+    for (int i = 0; i < IPT; ++i) {
+      const int k = i * 1024 + tid;
+      const unsigned half = (unsigned)((upper >> i) & 1ull);
+      const unsigned pos = atomicAdd(&bins[half * kSplitBins + bin_of(p[(size_t)k * 3 + 1], ymin, sy)], 1u);
+      part_idx[pos] = k;                               // positions [q 16384, (q + 1) 16384) = part q (x half, then y half)
+    }
   }
   for (int w = tid; w < exch_words; w += 1024) exch[(size_t)scene * exch_words + w] = 0ull;
-  // the error word is STICKY: it is cleared when the workspace is created (zero-filled by the caller) and by
-  // det6d_fps_fused_status once it has been read, never by a launch — a later launch must not hide an earlier failure
-  (void)err;
-}
-
-// ---- pre-pass 2: the 16 points of a lane ordered by the reference's tie key (strict '>' of the scan keeps the right one)
-__global__ __launch_bounds__(512) void coop_group_order_kernel(long long total_groups, int n, int log2s, unsigned *__restrict__ perm) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= total_groups) return;
-  unsigned *p = perm + g * 16;
-  unsigned v[16], key[16];
-  for (int i = 0; i < 16; ++i) { v[i] = p[i]; key[i] = co_tie_key((int)v[i], log2s); }
-  for (int i = 1; i < 16; ++i) {
-    const unsigned vi = v[i], ki = key[i];
-    int j = i;
-    while (j > 0 && key[j - 1] > ki) { v[j] = v[j - 1]; key[j] = key[j - 1]; --j; }
-    v[j] = vi; key[j] = ki;
-  }
-  for (int i = 0; i < 16; ++i) p[i] = v[i];
+  // (the error word of the workspace is STICKY: it is cleared when the workspace is created (zero-filled by the caller) and by
+  // det6d_fps_fused_status once it has been read, never by a launch — a later launch must not hide an earlier failure)
 }
 
 template <int LO, int HI, int N>
@@ -595,31 +641,17 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
 }
 
 struct CoopLayout {
-  size_t keys_in, keys_out, vals_in, vals_out, cub, exch, err, total;
-  size_t cub_bytes;
+  size_t part_idx, perm, exch, err, total;
 };
-
-int scene_bits(int b) {
-  int bits = 0;
-  while ((1 << bits) < b) ++bits;
-  return bits;
-}
 
 CoopLayout coop_layout(int b, int n) {
   CoopLayout L;
   const size_t items = (size_t)b * n;
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  size_t cub = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
-                                     (unsigned *)nullptr, (unsigned)items, 0, 20 + scene_bits(b), (hipStream_t)0);
-  L.cub_bytes = cub;
   size_t off = 0;
   L.err = off; off = align(off + 256);          // first: its offset must not depend on b (a workspace serves launches of fewer scenes)
-  L.keys_in = off; off = align(off + items * 4);
-  L.keys_out = off; off = align(off + items * 4);
-  L.vals_in = off; off = align(off + items * 4);
-  L.vals_out = off; off = align(off + items * 4);
-  L.cub = off; off = align(off + cub);
+  L.part_idx = off; off = align(off + items * 4);
+  L.perm = off; off = align(off + items * 4);
   L.exch = off; off = align(off + (size_t)b * coop_multi_words(4, kMultiCands) * 8);    // (covers the one-pick kernel's 2 x 4 x 8 words too)
   L.total = off;
   return L;
@@ -637,28 +669,26 @@ long long det6d_fps_coop_workspace_bytes(int b, int n) {
 
 // D-FPS of b scenes of n = 32768 / 65536 points with fresh min-distances; `workspace` of
 // det6d_fps_coop_workspace_bytes(b, n) bytes (256-byte aligned)
+int det6d_fps_cell_sort_parts(int subscenes, int parts, int log2s, long long xyz_bstride, const float *xyz, const int *src, int *perm,
+                              hipStream_t stream);      // fps_cells.hip
+
 int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream) {
   if (!det6d_fps_coop_handles(n) || b <= 0 || b > 4096 || !workspace || ((uintptr_t)workspace & 255)) return DET6D_EINVAL;
   const CoopLayout L = coop_layout(b, n);
   char *ws = (char *)workspace;
-  unsigned *keys_in = (unsigned *)(ws + L.keys_in), *keys_out = (unsigned *)(ws + L.keys_out);
-  unsigned *vals_in = (unsigned *)(ws + L.vals_in), *vals_out = (unsigned *)(ws + L.vals_out);
+  int *part_idx = (int *)(ws + L.part_idx);
+  unsigned *vals_out = (unsigned *)(ws + L.perm);
   unsigned long long *exch = (unsigned long long *)(ws + L.exch);
   int *err = (int *)(ws + L.err);
   const int parts = n / kPartPoints;
   static const int multi = det6d_env_int("DET6D_FPS_COOP_MULTI", 1);      // experiments build: 0 = the one-pick kernel
   const int exch_words = multi ? (int)coop_multi_words(parts, kMultiCands) : 2 * parts * kSlotWords;
-  hipLaunchKernelGGL(coop_keys_kernel, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, keys_in, vals_in, exch, exch_words, err);
-  size_t cub = L.cub_bytes;
-  const hipError_t sort_rc = hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub, keys_in, keys_out, vals_in, vals_out,
-                                                                (unsigned)((size_t)b * n), 0, 20 + scene_bits(b), stream);
-  if (sort_rc != hipSuccess) {
-    det6d_set_error("det6d_fps (cooperative: radix sort)", sort_rc);
-    return DET6D_ELAUNCH;
-  }
-  const long long groups = (long long)b * n / 16;
-  hipLaunchKernelGGL(coop_group_order_kernel, dim3((unsigned)((groups + 511) / 512)), dim3(512), 0, stream, groups, n, log2s, vals_out);
+  // pre-pass: spatial parts of 16384 points, then the single-workgroup sampler's k-d order inside every part
+  if (parts == 4) hipLaunchKernelGGL(coop_split_kernel<4>, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, part_idx, exch, exch_words);
+  else hipLaunchKernelGGL(coop_split_kernel<2>, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, part_idx, exch, exch_words);
+  const int sort_rc = det6d_fps_cell_sort_parts(b * parts, parts, log2s, xyz_bstride, xyz, part_idx, (int *)vals_out, stream);
+  if (sort_rc != DET6D_OK) return sort_rc;
   const int grid = 8 * parts * ((b + 7) / 8);
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;

@@ -35,13 +35,23 @@ def family(name):
     return fam
 
 
-sums = collections.defaultdict(lambda: collections.defaultdict(float))
-disp = collections.defaultdict(set)
+# Only the STEADY-STATE part of the run is summed: the dispatches between the 30th and the 70th percentile of the dispatch
+# sequence lie inside the continuous stream of 32-scene passes (the prime, the cold run, the one-batch latency legs and the
+# eager self-check passes are at the ends), so "per pass" below is per 32-scene pass of the timed region.
+rows = []
 for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        fam = family(r.get('Kernel_Name', ''))
-        sums[fam][r['Counter_Name']] += float(r['Counter_Value'])
-        disp[fam].add(r.get('Dispatch_Id'))
+        rows.append((int(r.get('Dispatch_Id') or 0), r.get('Kernel_Name', ''), r['Counter_Name'], float(r['Counter_Value'])))
+ids = sorted({r[0] for r in rows})
+lo_id, hi_id = ids[int(0.30 * len(ids))], ids[int(0.70 * len(ids))]
+sums = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
+for d_id, name, ctr, val in rows:
+    if not (lo_id <= d_id < hi_id):
+        continue
+    fam = family(name)
+    sums[fam][ctr] += val
+    disp[fam].add(d_id)
 passes = len(disp.get('pack_points', ())) or 1
 res = {'passes_profiled': passes, 'scenes_per_pass': bench.get('config', {}).get('scenes_per_pass'),
        'bench_under_profiler': {k: bench.get(k) for k in ('value', 'ms_per_step', 'selfcheck') if k in bench}}

@@ -325,6 +325,30 @@ def test_ball_query_pair_matches_two_queries(ext, oracle_ops, n, m, sa, sb):
         np.testing.assert_array_equal(ib.cpu().numpy(), oib)
 
 
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 256), (16384, 700), (2048, 300)])
+def test_weighted_sampler_fp32_scoring_and_its_exact_double_fallback(ext, oracle_ops, n, m):
+    """S-FPS through det6d_fps_fused (round 5): scenes whose weights are all >= 1e-12 are scored with one fp32 multiply per
+    point (exactly float(double(t) * double(w)): the product of two floats is exact in double); a scene holding a weight below
+    1e-12 (sigmoid(score) ** gamma underflowing it) or a NaN weight hands itself over to the exact-double launch behind.
+    Scenes of both kinds in ONE call, against the oracle's restatement of sampling_gpu.cu:419-540."""
+    fused = ext[2]
+    b = 5
+    pts = make_batch(170 + n, b, n, dup_frac=0.1)
+    xyz = np.ascontiguousarray(pts[..., :3])
+    rng = np.random.default_rng(n + m)
+    scores = (rng.normal(size=(b, n)) * 3).astype(np.float32)
+    scores[1, rng.choice(n, 40, replace=False)] = -40.0          # sigmoid -> 4e-18 < 1e-12: clamped in double by the reference
+    scores[2, 17] = np.nan                                        # max(NaN, 1e-12) = 1e-12 (sampling_gpu.cu:466)
+    scores[3] = -60.0                                             # every weight below the clamp
+    scores[4, :] = 50.0                                           # every weight 1.0: ties everywhere -> the reference's tie order
+    for gamma in (1.0, 2.5):
+        got = torch.full((b, m + 3), -5, dtype=torch.int32, device="cuda")
+        fused.fps_fused(dev(xyz), 0, n, m, dev(scores), gamma, got, 3)
+        want = np.full((b, m + 3), -5, np.int32)
+        oracle_ops.fps_fused(xyz, 0, n, m, scores, gamma, want, 3)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 def test_fused_sampler_and_helpers(ext, oracle_ops):
     """det6d_fps_fused (range slice + sigmoid**gamma + 1e10 init + offset), gather_centres, with_batch_index, pack"""
     fused = ext[2]
