@@ -180,9 +180,10 @@ def family_saturated(replay, n_streams=16, reps=24, streams=None):
     torch.cuda.synchronize()
     for si, st in enumerate(streams):   # every stream starts at another launch of the pass, as passes in flight do
         own = {}
-        for _, out, _ in replay:
-            if out.data_ptr() not in own:
-                own[out.data_ptr()] = out.clone()
+        for entry in replay:
+            for t in [entry[1]] + list(entry[3] if len(entry) > 3 else []):      # outputs + per-replay private tensors (ticket headers)
+                if t.data_ptr() not in own:
+                    own[t.data_ptr()] = t.clone()
         keep.append(own)
 
         def ptr_of(t, own=own):
@@ -191,8 +192,8 @@ def family_saturated(replay, n_streams=16, reps=24, streams=None):
         g = torch.cuda.CUDAGraph()
         rot = (si * len(replay)) // n_streams
         with torch.cuda.graph(g, stream=st):
-            for issue, _, _ in replay[rot:] + replay[:rot]:
-                issue(ptr_of)
+            for entry in replay[rot:] + replay[:rot]:
+                entry[0](ptr_of)
         graphs.append(g)
 
     def run(k):

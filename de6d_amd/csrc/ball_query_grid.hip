@@ -54,11 +54,24 @@ __device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell,
   return (int)f;
 }
 
+// PACKED (n <= 32768): two 16-bit counters per LDS word (a counter never exceeds n, so no carry crosses the halves): 33 KB of
+// LDS instead of 66 — a workgroup of this kernel then fits on a CU beside the head's wide group kernel (99 KB); with 66 KB it
+// had to wait for a CU without one, holding its hardware queue's dispatch slot meanwhile.
+template <bool PACKED>
 __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, float cell, const float *__restrict__ xyz,
                                                                       GridHeader *__restrict__ hdr,
                                                                       int *__restrict__ cell_start,
                                                                       float4 *__restrict__ sorted_pts) {
-  __shared__ int counts[kGridCells];
+  __shared__ unsigned counts[PACKED ? kGridCells / 2 : kGridCells];
+  auto cget = [&](int c) -> int { return PACKED ? (int)((counts[c >> 1] >> (16 * (c & 1))) & 0xffffu) : (int)counts[c]; };
+  auto cset = [&](int c, int v) {          // (only ever called by the one thread that owns cells c and c ^ 1)
+    if (PACKED) counts[c >> 1] = (counts[c >> 1] & ~(0xffffu << (16 * (c & 1)))) | ((unsigned)v << (16 * (c & 1)));
+    else counts[c] = (unsigned)v;
+  };
+  auto cadd = [&](int c) -> int {          // counter of cell c += 1, returns the old value
+    if (PACKED) return (int)((atomicAdd(&counts[c >> 1], 1u << (16 * (c & 1))) >> (16 * (c & 1))) & 0xffffu);
+    return (int)atomicAdd(&counts[c], 1u);
+  };
   __shared__ float red[kBuildThreads / 64];
   __shared__ int wave_tot[kBuildThreads / 64];
   const int tid = threadIdx.x;
@@ -92,19 +105,20 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
     h.ox = xmin; h.oy = ymin; h.inv_cell = inv; h.nx = nx; h.ny = ny; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     hdr[blockIdx.x] = h;
   }
-  for (int c = tid; c < ncells; c += kBuildThreads) counts[c] = 0;
+  for (int c = tid; c < (PACKED ? (ncells + 1) / 2 : ncells); c += kBuildThreads) counts[c] = 0u;
   __syncthreads();
   for (int k = tid; k < n; k += kBuildThreads) {
     const int cx = cell_coord(xyz[(size_t)k * 3 + 0], xmin, inv, nx);
     const int cy = cell_coord(xyz[(size_t)k * 3 + 1], ymin, inv, ny);
-    atomicAdd(&counts[cy * nx + cx], 1);
+    cadd(cy * nx + cx);
   }
   __syncthreads();
-  // exclusive scan of counts[0..ncells): each thread owns a contiguous chunk
-  const int chunk = (ncells + kBuildThreads - 1) / kBuildThreads;
-  const int c0 = tid * chunk, c1 = min(c0 + chunk, ncells);
+  // exclusive scan of the counts of cells [0, ncells): each thread owns a contiguous chunk (an EVEN number of cells, so that
+  // the two counters of a packed word belong to one thread)
+  const int chunk = ((ncells + kBuildThreads - 1) / kBuildThreads + 1) & ~1;
+  const int c0 = min(tid * chunk, ncells), c1 = min(c0 + chunk, ncells);
   int local = 0;
-  for (int c = c0; c < c1; ++c) local += counts[c];
+  for (int c = c0; c < c1; ++c) local += cget(c);
   int incl = local;
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -118,9 +132,9 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   int run = base + incl - local;
   for (int c = c0; c < c1; ++c) {
-    const int cnt = counts[c];
+    const int cnt = cget(c);
     cell_start[c] = run;
-    counts[c] = run;                               // becomes the scatter cursor
+    cset(c, run);                                  // becomes the scatter cursor (PACKED: run < n <= 32768 fits 16 bits)
     run += cnt;
   }
   if (tid == 0) cell_start[ncells] = n;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(kBuildThreads) void bq_grid_build_kernel(int n, flo
   for (int k = tid; k < n; k += kBuildThreads) {
     const int cx = cell_coord(xyz[(size_t)k * 3 + 0], xmin, inv, nx);
     const int cy = cell_coord(xyz[(size_t)k * 3 + 1], ymin, inv, ny);
-    const int pos = atomicAdd(&counts[cy * nx + cx], 1);
+    const int pos = cadd(cy * nx + cx);
     sorted_pts[pos] = make_float4(xyz[(size_t)k * 3 + 0], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2], __int_as_float(k));
   }
 }
@@ -175,6 +189,7 @@ __device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restr
 //     saves that builder's counting launch.
 constexpr int kListCap = 128;
 constexpr int kLaneThreads = 256;
+constexpr int kWalkShipped = 2;               // candidates a lane fetches per step of its walk
 constexpr int kLightCap = 192;               // most candidates a lane walks by itself (experiments build: DET6D_BQ_LIGHT_CAP)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -264,7 +279,7 @@ struct QueryArgs {
   const float4 *sorted_pts;
   int *cnt[2], *idx[2];
   CompactCountArgs count[2];
-  int light_cap;
+  int light_cap, fixed_cut;
 };
 
 // l mod c for 0 <= l < 4096, 1 <= c <= 64 (rc ~ 1 / c): the quotient estimate is exact or one short
@@ -274,7 +289,7 @@ __device__ __forceinline__ int small_mod(int l, int c, float rc) {
   return r >= c ? r - c : r;
 }
 
-template <typename LT, bool PAD>
+template <typename LT, bool PAD, int kWalk>
 __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const QueryArgs qa) {
   extern __shared__ __align__(16) unsigned char lane_lists_raw[];     // (ns_a + ns_b) x 256 entries
   __shared__ int lists[kLaneThreads / 64][2][kListCap];
@@ -307,9 +322,11 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
   const int n0 = end[0] - beg[0], n01 = n0 + end[1] - beg[1], cand = n01 + end[2] - beg[2];
   // Light or heavy, decided per WAVE: a wave walks its light lanes in lockstep, so the walk costs the wave max(cand of its
   // light lanes) steps of ~40 vector instructions whatever the other lanes hold, and a heavy centre ~300 for the wave.  The
-  // cut T that minimises  40 T + 300 #(cand > T)  over a few candidates (six ballots, scalar arithmetic) keeps a sparse wave
+  // cut T that minimises  80 T + 300 #(cand > T)  over a few candidates (seven ballots, scalar arithmetic) keeps a sparse wave
   // from following one dense centre through 200 steps, and lets a uniformly dense wave (65536-point scenes: ~70 candidates
-  // per centre) walk instead of taking 64 turns.
+  // per centre) walk instead of taking 64 turns.  (80 rather than 40 per step: a step is also a dependent L2 round trip, and
+  // the launch ends with its longest walk — with 40 the first layer's query took 153 us on an idle chip, with a cut pinned at
+  // 32 or 48 it takes 85; scripts/r05/gpu_t6.sh.)
   int cut = 0;
   {
     int best_cost = 0x7fffffff;
@@ -318,7 +335,8 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
       constexpr int kCuts[7] = {16, 32, 48, 64, 96, 128, 192};
       const int T = kCuts[t];
       if (T > qa.light_cap && t > 0) break;
-      const int cost = 40 * T + 300 * (int)__popcll(__ballot(cand > T));
+      if (qa.fixed_cut > 0 && T != qa.fixed_cut) continue;      // (experiments build: DET6D_BQ_CUT pins the cut)
+      const int cost = 80 * T + 300 * (int)__popcll(__ballot(cand > T));
       if (cost < best_cost) { best_cost = cost; cut = T; }
     }
   }
@@ -329,7 +347,6 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
   // ---- light centres: lane = centre, kWalk candidates per step (their records are fetched together: the walk is a chain of
   // L2 round trips, not of arithmetic)
   {
-    constexpr int kWalk = 4;
     const float rin2_a = qa.rin2_a, rout2_a = qa.rout2_a, rin2_b = qa.rin2_b, rout2_b = qa.rout2_b;
     for (int j0 = 0; __ballot(j0 < walk) != 0ull; j0 += kWalk) {
       float4 c[kWalk];
@@ -474,8 +491,8 @@ static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int
   off += ((size_t)b * (kGridCells + 1) * 4 + 63) / 64 * 64;
   float4 *sorted_pts = (float4 *)(ws + off);
   const float rmax = rout_a > rout_b ? rout_a : rout_b;
-  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start,
-                     sorted_pts);
+  if (n <= 32768) hipLaunchKernelGGL(bq_grid_build_kernel<true>, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start, sorted_pts);
+  else hipLaunchKernelGGL(bq_grid_build_kernel<false>, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start, sorted_pts);
   QueryArgs qa;
   qa.n = n; qa.m = m;
   qa.rin2_a = rin_a * rin_a; qa.rout2_a = rout_a * rout_a; qa.ns_a = ns_a;
@@ -485,18 +502,30 @@ static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int
   for (int g = 0; g < 2; ++g) qa.count[g] = count ? count[g] : CompactCountArgs{0, 0, 0, nullptr};
   static const int light_cap = det6d_env_int("DET6D_BQ_LIGHT_CAP", kLightCap);
   qa.light_cap = light_cap < 0 ? 0 : light_cap;
+  static const int fixed_cut = det6d_env_int("DET6D_BQ_CUT", 0);
+  qa.fixed_cut = fixed_cut;
   // index rows leave as 16-byte stores when nsample is a multiple of 4 (idx rows are then 16-byte aligned like their buffers)
   if (((ns_a & 3) == 0 && ((uintptr_t)idx_a & 15)) || ((ns_b & 3) == 0 && ((uintptr_t)idx_b & 15))) return DET6D_EINVAL;
   const bool narrow = n <= 65536;                  // point indices fit 16 bits: half the LDS per workgroup
   const size_t lds = (size_t)(ns_a + ns_b) * kLaneThreads * (narrow ? 2 : 4);
   const dim3 grid(det6d_divup(m, kLaneThreads), b), block(kLaneThreads);
-#define D6_BQ_LAUNCH(LT, PAD)                                                               \
-  do {                                                                                      \
-    DET6D_MAX_DYNAMIC_LDS((bq_grid_query_kernel<LT, PAD>), 2 * kMaxNs * kLaneThreads * 4);   \
-    hipLaunchKernelGGL((bq_grid_query_kernel<LT, PAD>), grid, block, lds, s, qa);            \
+#define D6_BQ_LAUNCH_W(LT, PAD, W)                                                             \
+  do {                                                                                         \
+    DET6D_MAX_DYNAMIC_LDS((bq_grid_query_kernel<LT, PAD, W>), 2 * kMaxNs * kLaneThreads * 4);   \
+    hipLaunchKernelGGL((bq_grid_query_kernel<LT, PAD, W>), grid, block, lds, s, qa);            \
   } while (0)
+#ifdef DET6D_EXPERIMENTS      // candidates fetched per walk step: 1 / 2 / 4 (DET6D_BQ_WALK) for A/B runs
+  static const int walk = det6d_env_int("DET6D_BQ_WALK", kWalkShipped);
+#define D6_BQ_LAUNCH(LT, PAD)                                                                  \
+  do {                                                                                         \
+    if (walk == 1) D6_BQ_LAUNCH_W(LT, PAD, 1); else if (walk == 2) D6_BQ_LAUNCH_W(LT, PAD, 2); else D6_BQ_LAUNCH_W(LT, PAD, 4); \
+  } while (0)
+#else
+#define D6_BQ_LAUNCH(LT, PAD) D6_BQ_LAUNCH_W(LT, PAD, kWalkShipped)
+#endif
   if (narrow) { if (pad) D6_BQ_LAUNCH(unsigned short, true); else D6_BQ_LAUNCH(unsigned short, false); }
   else { if (pad) D6_BQ_LAUNCH(int, true); else D6_BQ_LAUNCH(int, false); }
+#undef D6_BQ_LAUNCH_W
 #undef D6_BQ_LAUNCH
   return det6d_check_launch(what);
 }

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void compact_place_kernel(int total, int n, in
       hdr[7] = total;
       hdr[8] = h_all[kClasses];
       hdr[9] = unaligned;
+      hdr[10] = 0;                   // tile ticket and exit counter of the persistent group kernels (mlp_group.hip: g_draw_ticket)
+      hdr[11] = 0;
     }
   }
   __syncthreads();

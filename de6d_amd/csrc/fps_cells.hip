@@ -79,14 +79,19 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
   // sample lands in (or within reach of) 1.3 of the 16 boxes on average.  A Morton curve cut into 16 equal runs gives 2.65: a
   // run that crosses a quadrant boundary of the curve has a box that spans both quadrants.
   // Two COUNTING sorts in LDS (histogram -> exclusive scan -> one atomic per point for its position): 1024 x bins decide the
-  // strip, n / 4 y bins per strip the position inside it.  The order inside a bin is whatever the atomics make it — any
+  // strip, n / 16 y bins per strip the position inside it.  The order inside a bin is whatever the atomics make it — any
   // permutation is correct, and exact duplicates (same bin) stay within a bin's few points of each other, which is what lets
   // sq_hide_lane_duplicates find most of them in one lane.  (Rounds 2-4 ran two block radix sorts here: 124 us for 16384 points.)
+  // LDS: 48 KB for 16384 points (4096 bins + 16-bit positions), so that a workgroup of this kernel fits on a CU beside the
+  // head's wide group kernel (99 KB) — rounds 2-4 held 32-bit positions and one y bin per point: 131 KB, which no CU running
+  // that kernel could take, and a pre-pass that waits for a CU keeps its hardware queue's dispatch slot while it waits.
   constexpr int N = 1024 * IPT;
-  constexpr int BY = N / 4;                    // y bins per strip: one point per bin on average
+  constexpr int BY = N / 16;                   // y bins per strip: four points per bin on average (8 cm of an 80 m scene)
+  constexpr int QB = IPT / 4;                  // y bins per thread in the scan (4 strips x BY = N / 4 bins = 1024 QB)
+  static_assert(IPT % 4 == 0 && 4 * BY >= 1024, "bins[] serves the 1024 x bins too");
   __shared__ unsigned scan_tmp[16];
-  __shared__ unsigned bins[N];                 // histogram, then running offsets (x pass: the first 1024)
-  __shared__ int sorted[N];
+  __shared__ unsigned bins[4 * BY];            // histogram, then running offsets (x pass: the first 1024)
+  __shared__ unsigned short sorted[N];
   __shared__ float red[4][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   xyz += (size_t)(blockIdx.x / parts) * xyz_bstride;
@@ -136,24 +141,24 @@ __global__ __launch_bounds__(1024) void cell_sort_kernel(int n, int log2s, long 
     bin[i] = (pos / (unsigned)(N / 4)) * (unsigned)BY + (unsigned)fy;
   }
   __syncthreads();
-  // ---- y inside the strips: N bins (strip-major), thread t scans bins t IPT .. t IPT + IPT - 1
+  // ---- y inside the strips: 4 BY bins (strip-major), thread t scans bins t QB .. t QB + QB - 1
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) bins[i * 1024 + tid] = 0u;
+  for (int i = 0; i < QB; ++i) bins[i * 1024 + tid] = 0u;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPT; ++i) atomicAdd(&bins[bin[i]], 1u);
   __syncthreads();
   {
-    unsigned cnt[IPT], total = 0u, base;
+    unsigned cnt[QB], total = 0u, base;
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) { cnt[i] = bins[tid * IPT + i]; total += cnt[i]; }
+    for (int i = 0; i < QB; ++i) { cnt[i] = bins[tid * QB + i]; total += cnt[i]; }
     base = block_exclusive_sum_1024(total, scan_tmp);
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) { bins[tid * IPT + i] = base; base += cnt[i]; }   // (every thread rewrites only its own bins)
+    for (int i = 0; i < QB; ++i) { bins[tid * QB + i] = base; base += cnt[i]; }   // (every thread rewrites only its own bins)
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) sorted[atomicAdd(&bins[bin[i]], 1u)] = i * 1024 + tid;
+  for (int i = 0; i < IPT; ++i) sorted[atomicAdd(&bins[bin[i]], 1u)] = (unsigned short)(i * 1024 + tid);
   __syncthreads();
   // The IPT consecutive positions of this thread are exactly the slots of ONE lane of the samplers: order them by the
   // reference's tie key here (the strict '>' of a lane's scan then keeps the right point among equal values), in registers.

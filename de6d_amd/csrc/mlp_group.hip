@@ -39,7 +39,32 @@ struct GroupArgs {
   float *y; int ldy; int col0;
   int pre;                                        // A/B switch: list entries of the next tile requested a K loop ahead
   int yvec;                                       // y rows are 16-byte aligned (ldy, col0 multiples of 4): vector stores allowed
+  int *ticket;                                    // compact rows: tile ticket + exit counter (hdr[10], hdr[11]); nullptr: static tiles
 };
+
+// ---- tiles by ticket (round 5) --------------------------------------------------------------------------------------------
+// The group kernels are persistent: one workgroup per CU (or 2-3) walks the 32-row tiles of the launch.  With a STATIC walk
+// (tile += gridDim.x) the launch ends with its slowest workgroup, and in the pipeline the CUs are not alike: ~30 of the 256
+// host a sampler workgroup (16 waves at raised priority for 2 ms), others a ball-query or list-builder wave — the wide head
+// group ran 1.5-1.6 ms per launch under load against 0.98 ms alone.  Now a workgroup takes its FIRST tile by its block index
+// and every further one from a ticket counter in the list header: fast CUs take more tiles.  The ticket of the next tile is
+// drawn at the top of the current one (its latency hides behind the gather), published through LDS by tile parity, so the
+// next tile's list entries can still be requested a K loop ahead.  The counter pair cleans itself: the last workgroup to leave
+// (exit counter == workgroups that had a tile) zeroes both, so a launch may be replayed without rebuilding the list
+// (bench: family_saturated); compact_place_kernel zeroes them too when it builds the list.  Results do not depend on which
+// workgroup computes a tile (a tile's outputs are a function of its rows; multi-part centres combine by an order-independent
+// integer max).
+__device__ __forceinline__ int g_draw_ticket(int *ticket, int grid) {
+  return grid + __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_leave(int *ticket, int workers) {
+  // (this thread's last ticket draw has returned — its value was used — before this add is issued)
+  const int gone = __hip_atomic_fetch_add(ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gone == workers - 1) {
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // ---- compact-row helpers (same conventions as mlp_chain.hip / linear.hip; see compact.hip for the list layout) ----
 __device__ __forceinline__ int g_class(int row0, int h1, int h2, int h3, int h4, int h5) {
@@ -403,17 +428,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
   D6_PHASE_DECL
   int e0, e1;
   group_row_entry<COMPACT, 2 * NW>(g, blockIdx.x, tid, e0, e1);
-  for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
+  __shared__ int next_tile_s[2];
+  int *const ticket = COMPACT ? g.ticket : nullptr;
+  for (int tile = blockIdx.x; tile < live_tiles;) {
 #ifdef DET6D_EXPERIMENTS
     ++ph_tiles;
 #endif
+    int drawn = 0;
+    if (ticket && tid == 0) drawn = g_draw_ticket(ticket, (int)gridDim.x);
     GroupLayer<C1, TN2, LD1> second;
     GroupLayer<C2, TN3, LD2> third;
     second.start(srd2, voff2, g.ldw2 * 4);
+    const int par = it & 1;
     int *tagbuf = tags + 32 * (it++ & 1);
     if (!g.pre) group_row_entry<COMPACT, 2 * NW>(g, tile, tid, e0, e1);
     group_layer1<C1, COMPACT, 2 * NW>(g, tile, tid, X1, tagbuf, e0, e1);
+    if (ticket && tid == 0) next_tile_s[par] = drawn;
     __syncthreads();
+    const int next_tile = ticket ? next_tile_s[par] : tile + (int)gridDim.x;
     D6_PHASE(0);
     // ---- layer 2: X2 = relu(X1 W2 + s2) ----
     {
@@ -444,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     D6_WAVE_T0;
     if (g.pre) {          // the next tile's list entries, a K loop ahead of its first layer (the last tile re-reads its own)
-      const int nt = tile + (int)gridDim.x;
+      const int nt = next_tile;
       group_row_entry<COMPACT, 2 * NW>(g, nt < live_tiles ? nt : tile, tid, e0, e1);
     }
     third.run(X2, srd3, voff3, g.ldw3 * 4, acc, l31, kh);
@@ -454,7 +486,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_g
     // no barrier here: the next tile's layer 1 writes X1, which every wave finished reading before the barrier above;
     // X2 is rewritten only after the next tile's first barrier, which no wave passes before it has left layer 3
     D6_PHASE(4);
+    tile = next_tile;
   }
+  if (ticket && tid == 0) g_leave(ticket, min((int)gridDim.x, live_tiles));
   D6_PHASE_END;
 }
 
@@ -555,12 +589,19 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
     for (int e = 0; e < 16; ++e) yc[((e & 3) + 8 * (e >> 2) + 4 * kh) * LDY] = d6_relu(acc2[0][e] + sh2);
   };
 
-  for (int tile = blockIdx.x; tile < live_tiles; tile += gridDim.x) {
+  __shared__ int next_tile_s[2];
+  int *const ticket = COMPACT ? g.ticket : nullptr;
+  for (int tile = blockIdx.x; tile < live_tiles;) {
+    int drawn = 0;
+    if (ticket && tid == 0) drawn = g_draw_ticket(ticket, (int)gridDim.x);     // tiles by ticket: see g_draw_ticket
+    const int par = it & 1;
     int *tagbuf = tags + 32 * (it++ & 1);
     int e0, e1;
     group_row_entry<COMPACT, 8>(g, tile, tid, e0, e1);
     group_layer1<C1, COMPACT, 8>(g, tile, tid, X1, tagbuf, e0, e1);
+    if (ticket && tid == 0) next_tile_s[par] = drawn;
     __syncthreads();
+    const int next_tile = ticket ? next_tile_s[par] : tile + (int)gridDim.x;
     f32x16 acc[TN3];
 #pragma unroll
     for (int j = 0; j < TN3; ++j)
@@ -582,7 +623,9 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
     group_pool_store<TN3, COMPACT>(g, tile, acc, sh3, wave * (C3 / 4), l31, kh, h1, h2, h3, h4, h5, tagbuf, scr);
     // no barrier here: X1 is rewritten by the next tile's layer 1, every wave is past its last second-layer chunk (the
     // barrier above); Y0 is rewritten after the next tile's first barrier, Y1 two barriers later
+    tile = next_tile;
   }
+  if (ticket && tid == 0) g_leave(ticket, min((int)gridDim.x, live_tiles));
 }
 
 template <int C1, int C2, int C3, bool COMPACT>
@@ -665,6 +708,10 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   g.pts = pts; g.ldpts = ldpts; g.ctr = ctr; g.ldctr = ldctr;
   g.idx = idx; g.n = n; g.m = m; g.ns = ns; g.cnt = cnt;
   g.hdr = hdr; g.crow_p = crow_p; g.crow_c = crow_c;
+  // tiles by ticket on compact lists (hdr[10], hdr[11]: zeroed by the list builder and by the kernels themselves); the
+  // experiments build keeps the static walk behind DET6D_GROUP_STATIC=1 for A/B runs
+  static const int static_tiles = det6d_env_int("DET6D_GROUP_STATIC", 0);
+  g.ticket = (hdr && !static_tiles) ? const_cast<int *>(hdr) + 10 : nullptr;
   g.y = y; g.ldy = ldy; g.col0 = col0;
   static const int pre_entries = det6d_env_int("DET6D_GROUP_PRE", 1);
   g.pre = pre_entries;

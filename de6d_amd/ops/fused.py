@@ -299,14 +299,19 @@ def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, c
     (w1, s1, c1, _), (w2, s2, c2, _), (w3, s3, c3, _) = layers
     if compact is not None:
         rows, hdr = compact.capacity, compact.hdr
-        tail = (None, 0, 0, 0, None, L.ptr(compact.hdr), L.ptr(compact.crow_p), L.ptr(compact.crow_c))
     else:
         b, m, ns = idx.shape
         rows, hdr = b * m * ns, b * m * ns
-        tail = (L.ptr(idx), rows_pts.shape[1], m, ns, L.ptr(cnt), None, None, None)
 
     def issue(ptr_of=None):
         y = L.ptr(out) if ptr_of is None else ctypes.c_void_p(ptr_of(out))
+        if compact is not None:
+            # (the kernel draws its tiles from a ticket counter inside the list header: a replay that runs CONCURRENTLY with
+            # others of the same launch — bench_legs.family_saturated — needs a header of its own)
+            h = L.ptr(compact.hdr) if ptr_of is None else ctypes.c_void_p(ptr_of(compact.hdr))
+            tail = (None, 0, 0, 0, None, h, L.ptr(compact.crow_p), L.ptr(compact.crow_c))
+        else:
+            tail = (L.ptr(idx), rows_pts.shape[1], m, ns, L.ptr(cnt), None, None, None)
         L.call("det6d_mlp_group3", rows, L.ptr(p), p.shape[-1], pcol0, L.ptr(w1), w1.shape[1], L.ptr(s1), c1, L.ptr(w2), w2.shape[1],
                L.ptr(s2), c2, L.ptr(w3), w3.shape[1], L.ptr(s3), c3, L.ptr(rows_pts), rows_pts.shape[-1], L.ptr(ctr), ctr.shape[-1],
                *tail, y, out.shape[-1], col0, L.stream_ptr())
@@ -315,7 +320,7 @@ def mlp_group3(p, pcol0, layers, rows_pts, ctr, out, col0, idx=None, cnt=None, c
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     if LINEAR_REPLAY is not None:
-        LINEAR_REPLAY.append((issue, out, (p, layers, rows_pts, ctr, out, idx, cnt, compact)))
+        LINEAR_REPLAY.append((issue, out, (p, layers, rows_pts, ctr, out, idx, cnt, compact), [compact.hdr] if compact is not None else []))
     issue()
     if ev is not None:
         ev[1].record()

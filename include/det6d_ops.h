@@ -419,7 +419,9 @@ int det6d_linear(const det6d_linear_args *args, det6d_stream_t stream);
  * s = max(smin, 2^ceil(log2 cnt)) slots of every centre gives the same pooled features bit for bit.
  *   cnt (B*m), idx (B,m,ns) as written by the ball queries;  ns, smin powers of two, smin <= ns <= 32;
  *   hdr (det6d_compact_hdr_ints(B*m)) i32: [0] live rows (multiple of 128), [1..6] end of the class regions s = 32,16,8,4,2,1,
- *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment;
+ *                 [7] centres, [8] sum of min(cnt, ns), [9] rows before alignment, [10], [11] tile ticket and exit counter of
+ *                 the persistent group kernels that consume the list (det6d_mlp_group3: zero between launches; a list must not
+ *                 feed two such launches at the same time);
  *   crow_p, crow_c (det6d_compact_rows_capacity(B*m, ns)) i32: point row / centre of every compact row
  *                 (crow_c: bit 30 set for an empty ball, bit 29 for a centre cut into several parts, -1 on
  *                 alignment rows).

@@ -577,6 +577,7 @@ ORACLE_API int det6d_oracle_compact_groups(int b, int n, int m, int ns, int smin
   hdr[0] = r;
   for (int c = 0; c < 6; ++c) hdr[1 + c] = start[c + 1];
   hdr[7] = total; hdr[8] = real; hdr[9] = unaligned;
+  hdr[10] = hdr[11] = 0;   /* tile ticket / exit counter of the HIP group kernels: zero whenever no kernel runs */
   for (int c = 0; c < 6; ++c)
     for (int q = start[c] + count[c] * (32 >> c); q < start[c + 1]; ++q) { crow_p[q] = 0; crow_c[q] = -1; }
   for (int i = 0; i < total; ++i) {
