@@ -69,7 +69,7 @@ sys.path.insert(0, ROOT)
 from de6d_amd.runtime import ScenePipeline, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd import synthetic  # noqa: E402
 from bench_legs import (MAIN_STREAMS, SAMPLER_STREAMS, coalesce_factor, compact_fill, index_kernel_rates,  # noqa: E402
-                        input_producer_rate, linear_roofline, pipeline_rate, selfcheck)
+                        input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, selfcheck)
 
 
 def synth_points(seed0, b, n, tilt=False, scene='uniform'):
@@ -171,6 +171,27 @@ def orchestrate(args):
                 line["roofline"]["raycast"] = {"scenes_per_s": ray["scenes_per_s"], "frac": ray["roofline"]["frac"],
                                                "achieved": ray["roofline"]["achieved"],
                                                "algorithmic_gflop_per_pass": ray["roofline"]["algorithmic_gflop_per_pass"]}
+        # Operating points (round-4 review item 7): the same engine with fewer passes in flight — less throughput, a fraction
+        # of the latency under load.  (main streams, sampler stages issued ahead): p50 / p99 of host issue -> in-order delivery.
+        pts = {}
+        for streams, ahead in ((4, 2), (4, 4), (8, 4)):
+            r = child_rate(args, {}, ['--streams', str(streams), '--prefetch', str(ahead)])
+            pts["%d main streams, %d ahead" % (streams, ahead)] = {k: r.get(k) for k in ("scenes_per_s", "latency_under_load_ms", "selfcheck", "error") if k in r}
+        pts["%d main streams, %d ahead (value)" % (args.streams, args.prefetch)] = {
+            "scenes_per_s": line["value"], "latency_under_load_ms": line.get("latency_under_load", {}).get("ms_p50_p99"), "selfcheck": line.get("selfcheck")}
+        line["operating_points"] = pts
+        line["config"]["operating_points_scenes_per_s_at_p50_ms"] = {
+            k: [v.get("scenes_per_s"), (v.get("latency_under_load_ms") or [None])[0]] for k, v in pts.items()}
+        # roofline.traffic measured in THIS run (two rocprofv3 --pmc child passes of this bench); the committed summary only as
+        # a fallback, named as such
+        if isinstance(line.get("roofline"), dict) and not args.no_roofline:
+            tr = measured_traffic(os.path.abspath(__file__), ['--cfg', args.cfg, '--points', str(args.points)])
+            if tr is not None:
+                line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = "measured in this run"
+                line["roofline"]["traffic_detail"] = tr
+            elif line["roofline"].get("traffic_source"):
+                line["roofline"]["traffic_source"] += " (committed summary: rocprofv3 --pmc failed or is missing in this run)"
         # the reference's timed loop includes load_data_to_gpu (core/tools/eval_utils/eval_utils.py:53-56): the same stream of
         # steps with every batch uploaded from pinned host memory on its pass's sampler stream.  Never `value`.
         line["h2d_inclusive"] = child_rate(args, {}, ['--h2d'],
@@ -521,6 +542,8 @@ def main():
             line["latency_b1"] = {"ms_per_frame": med, "ms_min_max": [lo, hi],
                                   "note": "ONE scene of %d points, one captured graph on one stream, idle chip, host launch -> "
                                           "detections on the host; median of 11" % n}
+            line["config"]["latency_b1_ms_per_frame"] = line["latency_b1"]["ms_per_frame"]
+            line["config"]["latency_ms_per_batch"] = line["latency"]["ms_per_batch"]
             del lat, lat1, one
         if world == 1 and not args.no_roofline:
             line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS)

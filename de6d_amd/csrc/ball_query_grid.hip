@@ -190,7 +190,7 @@ __device__ __forceinline__ int keep_smallest(int *__restrict__ lst, int *__restr
 constexpr int kListCap = 128;
 constexpr int kLaneThreads = 256;
 constexpr int kWalkShipped = 2;               // candidates a lane fetches per step of its walk
-constexpr int kLightCap = 192;               // most candidates a lane walks by itself (experiments build: DET6D_BQ_LIGHT_CAP)
+constexpr int kLightCap = 96;                // most candidates a lane walks by itself (experiments build: DET6D_BQ_LIGHT_CAP)
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
   const int n0 = end[0] - beg[0], n01 = n0 + end[1] - beg[1], cand = n01 + end[2] - beg[2];
   // Light or heavy, decided per WAVE: a wave walks its light lanes in lockstep, so the walk costs the wave max(cand of its
   // light lanes) steps of ~40 vector instructions whatever the other lanes hold, and a heavy centre ~300 for the wave.  The
-  // cut T that minimises  80 T + 300 #(cand > T)  over a few candidates (seven ballots, scalar arithmetic) keeps a sparse wave
+  // cut T that minimises  80 T + 300 #(cand > T)  over a few candidates (five ballots, scalar arithmetic) keeps a sparse wave
   // from following one dense centre through 200 steps, and lets a uniformly dense wave (65536-point scenes: ~70 candidates
   // per centre) walk instead of taking 64 turns.  (80 rather than 40 per step: a step is also a dependent L2 round trip, and
   // the launch ends with its longest walk — with 40 the first layer's query took 153 us on an idle chip, with a cut pinned at
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(kLaneThreads) void bq_grid_query_kernel(const Query
   {
     int best_cost = 0x7fffffff;
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      constexpr int kCuts[7] = {16, 32, 48, 64, 96, 128, 192};
+    for (int t = 0; t < 5; ++t) {
+      constexpr int kCuts[5] = {16, 32, 48, 64, 96};
       const int T = kCuts[t];
       if (T > qa.light_cap && t > 0) break;
       if (qa.fixed_cut > 0 && T != qa.fixed_cut) continue;      // (experiments build: DET6D_BQ_CUT pins the cut)

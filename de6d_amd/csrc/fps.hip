@@ -202,9 +202,14 @@ __device__ __forceinline__ void pick_slot(int ws, int wl, const float (&px)[N], 
 // kept in this build: .amdhsa_float_denorm_mode_32 3): FASTW scores a point with one v_mul_f32 instead of convert / fp64
 // multiply / convert and holds the weights as 32-bit values (SLOTS fewer registers).  A scene that holds a weight below
 // 1e-12 — or a NaN weight, which the reference's max() turns into 1e-12 — cannot take that form: the FASTW launch writes
-// flags[scene] = 1 for it and returns, and the exact-double launch behind it (GUARDED: it returns at once for every scene
-// whose flag is 0) samples that scene.  Two kernels rather than two paths in one: with both paths inlined the allocator sizes
-// the kernel for their union (fat<9, 32>: 202 -> 256 registers + 464 bytes of scratch per lane).
+// flags[scene] = 1 for it and returns, and the GUARDED exact-double launch behind it (fps_mem_kernel: it returns at once for
+// every scene whose flag is 0) samples that scene — many times slower (min-distances and weights in memory), exact, and rare: a
+// confidence logit below -27.6.  Why two kernels, and why the memory-resident one behind: with both scoring forms inlined in
+// one kernel the allocator sizes it for their union (fat<9, 32>: 202 -> 256 registers + 464 bytes of scratch per lane; with
+// the exact form as a rolled loop over memory inside the kernel the fp32 form lost its gain: 358 -> 393 us); and a guarded
+// launch must be CHEAP TO PLACE — a launch that only looks at a flag still needs its workgroup's registers on a CU before it
+// may start: the register-resident exact kernel (202 registers x 8 waves) waited 4.3 ms on average for them in the
+// 65536-point pipeline, the memory-resident one holds ~20 registers per lane.
 template <int LOG2T, int SLOTS, bool WEIGHTED, bool FASTW = false>
 __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int log2s, int log2pptv,
                                                              const float *__restrict__ xyz,
@@ -213,7 +218,6 @@ __global__ __launch_bounds__(1 << LOG2T) void fps_fat_kernel(int n, int m, int l
                                                              int *__restrict__ idxs, const FpsView vw,
                                                              int *__restrict__ flags = nullptr) {
   static_assert(WEIGHTED || !FASTW, "FASTW is a form of the weighted sampler");
-  if (WEIGHTED && !FASTW && flags != nullptr && flags[(size_t)blockIdx.x * vw.temp_bstride] == 0) return;   // GUARDED
   static_assert(SLOTS >= 2 && SLOTS % 2 == 0, "pairs");
   constexpr int T = 1 << LOG2T;
   constexpr int NW = T / 64;
@@ -355,8 +359,15 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int log2s,
                                                        const float *__restrict__ xyz,
                                                        const float *__restrict__ weights,
                                                        float *__restrict__ temp,
-                                                       int *__restrict__ idxs, const FpsView vw) {
+                                                       int *__restrict__ idxs, const FpsView vw,
+                                                       const int guarded = 0) {
   __shared__ Slot slots[2][16];
+  if (guarded) {      // behind an fp32-scoring launch (fps_fat_kernel<.., FASTW>): only the scenes it handed over (flag = the
+                      // first word of the scene's scratch, which this kernel is about to initialise: read it first)
+    const int flag = reinterpret_cast<const int *>(temp)[(size_t)blockIdx.x * vw.temp_bstride];
+    if (flag == 0) return;
+    __syncthreads();
+  }
   const int S = 1 << log2s;
   const int h = threadIdx.x;
   const int lane = h & 63;
@@ -451,11 +462,14 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
     int lp = 0;                                                                                \
     while ((1 << lp) < ppt) ++lp;                                                              \
     static const unsigned hog = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W>, 1024);        \
-    if (flags)                                                                                 \
+    if (flags) {                                                                               \
       hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
                          lp, xyz, weights, temp, idx, vw, flags);                              \
-    hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
-                       lp, xyz, weights, temp, idx, vw, flags);                                \
+      hipLaunchKernelGGL((fps_mem_kernel<W>), grid, dim3(S < 64 ? 64 : S), 0, stream, n, m, log2s, xyz, weights, temp, idx, vw, 1); \
+    } else {                                                                                   \
+      hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
+                         lp, xyz, weights, temp, idx, vw, nullptr);                            \
+    }                                                                                          \
     return det6d_check_launch("det6d_fps");                                                    \
   } while (0)
   if (n == S * ppt && (ppt & (ppt - 1)) == 0) {
