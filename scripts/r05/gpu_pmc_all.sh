@@ -1,0 +1,5 @@
+# counters of one eager pass on the three workloads: benchmark scenes, ray-cast scenes, 65536-point scenes (BASELINE configs[4] per-GPU share)
+sfx=${1:-z}
+bash scripts/r05/gpu_pmc.sh r05${sfx}_z
+bash scripts/r05/gpu_pmc.sh r05${sfx}_beam --scene beam
+BATCH=8 STEPS=4 bash scripts/r05/gpu_pmc.sh r05${sfx}_65536 --cfg synthetic_models/det6d_65536.yaml --points 65536
