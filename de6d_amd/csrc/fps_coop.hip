@@ -689,7 +689,18 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   else hipLaunchKernelGGL(coop_split_kernel<2>, dim3(b), dim3(1024), 0, stream, n, xyz_bstride, xyz, part_idx, exch, exch_words);
   const int sort_rc = det6d_fps_cell_sort_parts(b * parts, parts, log2s, xyz_bstride, xyz, part_idx, (int *)vals_out, stream);
   if (sort_rc != DET6D_OK) return sort_rc;
-  const int grid = 8 * parts * ((b + 7) / 8);
+  // The parts of a scene poll each other, so all workgroups of a launch must be resident together: ONE launch never asks for
+  // more than one 1024-thread workgroup per CU — more scenes are sampled chunk by chunk on the stream (launches of a stream do
+  // not overlap), so that a single call cannot starve itself whatever `b` is.  (Two calls in flight on DIFFERENT streams are
+  // still the caller's to bound: det6d_ops.h, ScenePipeline does it.)
+  static int cus = 0;
+  if (cus <= 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int chunk = std::max(8, cus / parts / 8 * 8);      // scenes per sampling launch (a multiple of 8: the block -> scene map)
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
   // (clamped like fps_seq.hip's: 0 would never advance a round, more than kCoopMaxPicks would write past the pick arrays in LDS)
@@ -697,26 +708,34 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
 #ifdef DET6D_EXPERIMENTS
   det6d_dbg_poison_lds_hook(stream);      // DET6D_DBG_POISON_LDS: fps_seq.hip
 #endif
-  if (multi) {
-    if (parts == 4)
-      hipLaunchKernelGGL((fps_coop_multi_kernel<4, kMultiCands>), dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, xyz, vals_out, idx, exch, err, allow_fast, max_picks);
-    else
-      hipLaunchKernelGGL((fps_coop_multi_kernel<2, kMultiCands>), dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride,
-                         idx_add, xyz, vals_out, idx, exch, err, allow_fast, max_picks);
-    return det6d_check_launch("det6d_fps (cooperative, multi-pick)");
-  }
+  for (int s0 = 0; s0 < b; s0 += chunk) {
+    const int bc = std::min(chunk, b - s0);
+    const int grid = 8 * parts * ((bc + 7) / 8);
+    const float *x0 = xyz + (size_t)s0 * xyz_bstride;
+    const unsigned *perm0 = vals_out + (size_t)s0 * n;
+    int *idx0 = idx + (size_t)s0 * idx_bstride;
+    unsigned long long *exch0 = exch + (size_t)s0 * exch_words;
+    if (multi) {
+      if (parts == 4)
+        hipLaunchKernelGGL((fps_coop_multi_kernel<4, kMultiCands>), dim3(grid), dim3(1024), 0, stream, bc, n, m, log2s, xyz_bstride, idx_bstride,
+                           idx_add, x0, perm0, idx0, exch0, err, allow_fast, max_picks);
+      else
+        hipLaunchKernelGGL((fps_coop_multi_kernel<2, kMultiCands>), dim3(grid), dim3(1024), 0, stream, bc, n, m, log2s, xyz_bstride, idx_bstride,
+                           idx_add, x0, perm0, idx0, exch0, err, allow_fast, max_picks);
+      continue;
+    }
 #ifdef DET6D_EXPERIMENTS
-  if (parts == 4)
-    hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err, allow_fast);
-  else
-    hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz,
-                       vals_out, idx, exch, err, allow_fast);
-  return det6d_check_launch("det6d_fps (cooperative)");
+    if (parts == 4)
+      hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(grid), dim3(1024), 0, stream, bc, n, m, log2s, xyz_bstride, idx_bstride, idx_add, x0,
+                         perm0, idx0, exch0, err, allow_fast);
+    else
+      hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(grid), dim3(1024), 0, stream, bc, n, m, log2s, xyz_bstride, idx_bstride, idx_add, x0,
+                         perm0, idx0, exch0, err, allow_fast);
 #else
-  return DET6D_EINVAL;
+    return DET6D_EINVAL;
 #endif
+  }
+  return det6d_check_launch(multi ? "det6d_fps (cooperative, multi-pick)" : "det6d_fps (cooperative)");
 }
 
 // byte offset of the (sticky) error word inside a cooperative workspace

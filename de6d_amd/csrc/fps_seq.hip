@@ -250,6 +250,42 @@ extern "C" __attribute__((visibility("default"))) int det6d_dbg_probe_lds(unsign
 }
 #endif
 
+#ifdef DET6D_EXPERIMENTS
+// What-if hook (scripts/r05/whatif_occupancy.py, never a result path): `blocks` workgroups of 16 waves that HOLD R registers per
+// lane and `lds` bytes of LDS for `usec` microseconds and issue nothing but s_sleep — the footprint of a sampler workgroup
+// without its instructions: what do 32 such workgroups per pass cost the pipeline, by footprint?
+namespace {
+template <int R>
+__global__ __launch_bounds__(1024) void occupy_kernel(int usec, float *sink) {
+  extern __shared__ float occ_lds[];
+  float r[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) r[i] = (float)(threadIdx.x + i);
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < (unsigned long long)usec * 100ull) {
+    __builtin_amdgcn_s_sleep(100);
+#pragma unroll
+    for (int i = 0; i < R; ++i) asm volatile("" : "+v"(r[i]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < R; ++i) s += r[i];
+  if (s == -1.f) { occ_lds[threadIdx.x] = s; sink[0] = occ_lds[0]; }
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int det6d_dbg_occupy(int blocks, int regs, int lds, int usec, float *sink, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+#define D6_OCC(R)                                                         \
+  do {                                                                    \
+    DET6D_MAX_DYNAMIC_LDS(occupy_kernel<R>, 160 * 1024);                  \
+    hipLaunchKernelGGL(occupy_kernel<R>, dim3(blocks), dim3(1024), lds, s, usec, sink); \
+  } while (0)
+  if (regs >= 96) D6_OCC(96); else if (regs >= 80) D6_OCC(80); else if (regs >= 56) D6_OCC(56); else if (regs >= 40) D6_OCC(40); else D6_OCC(16);
+#undef D6_OCC
+  return det6d_check_launch("det6d_dbg_occupy");
+}
+#endif
+
 // Called by fps_cells.hip's launcher after the Morton sort and the lane-group ordering (groups of 16 positions).
 int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                          const float *xyz, const int *perm, int *idx, hipStream_t stream) {

@@ -295,9 +295,11 @@ long long det6d_fps_fused_workspace_bytes(int b, int n);
  * det6d_fps_fused_status_offset: byte offset of that word from `temp` (so that a pipeline can copy it to pinned memory
  *   next to its other results without a synchronisation of its own), -1 when the sampler that (b, n, temp_bytes) selects
  *   cannot fail after its launch.
- * Co-residency is the caller's to bound: cooperative launches in flight at the same time must not ask for more than one
- * workgroup per CU in total (2 / 4 x scenes each), otherwise partially dispatched launches can starve each other until
- * the time-out (de6d_amd/runtime.py: ScenePipeline keeps them on few enough streams). */
+ * Co-residency: ONE call never asks for more than one workgroup per CU at a time (a call over more scenes than CUs / parts
+ * samples them chunk by chunk on its stream), so a call cannot starve itself whatever b is.  Calls in flight at the same
+ * time on DIFFERENT streams are the caller's to bound: together they must not ask for more than one workgroup per CU
+ * (2 / 4 x scenes each), otherwise partially dispatched launches can starve each other until the time-out
+ * (de6d_amd/runtime.py: ScenePipeline keeps them on few enough streams). */
 int det6d_fps_fused_status(int b, int n, const float *temp, long long temp_bytes, det6d_stream_t stream);
 long long det6d_fps_fused_status_offset(int b, int n, const float *temp, long long temp_bytes);
 int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const float *xyz, const float *scores,

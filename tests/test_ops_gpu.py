@@ -503,6 +503,25 @@ def test_cooperative_sampler_for_large_scenes():
     assert "ALL True" in out.stdout, out.stdout
 
 
+def test_cooperative_sampler_call_over_more_scenes_than_the_chip_holds(ext, oracle_ops):
+    """one det6d_fps_fused call over 72 scenes of 65536 points = 288 cooperating workgroups on a 256-CU chip: the call samples
+    them in chunks of one workgroup per CU (round-4 review: a C-ABI caller could starve itself until the 2 s time-out); picks
+    equal the oracle's on a few scenes of every chunk, the status word stays clear"""
+    fused = ext[2]
+    b, n, m = 72, 65536, 48
+    rng = np.random.default_rng(99)
+    base = make_batch(640, 3, n)[..., :3]
+    xyz = np.ascontiguousarray(base[np.arange(b) % 3] + rng.normal(size=(b, 1, 3)).astype(np.float32) * np.float32(0.01))
+    idx = torch.full((b, m), -1, dtype=torch.int32, device="cuda")
+    ws = fused.fps_workspace(b, n)
+    fused.fps_fused(dev(xyz), 0, n, m, None, 1.0, idx, 0, temp=ws)
+    fused.fps_status(b, n, ws)                                   # raises if a workgroup gave up waiting for its partners
+    got = idx.cpu().numpy()
+    assert (got >= 0).all() and (got < n).all() and (got[:, 0] == 0).all()
+    for s in (0, 1, 63, 64, 65, 71):
+        np.testing.assert_array_equal(got[s], oracle_ops.fps(xyz[s:s + 1], m)[0], err_msg="scene %d" % s)
+
+
 def test_ball_query_grid_adversarial(ext, oracle_ops):
     """grid search corner cases: centres outside the cloud, everything in one cell, outliers that stretch
     the bounding box past 128 cells, vertical stacks (the grid is 2-D), non-finite points"""
