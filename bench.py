@@ -15,9 +15,10 @@ region.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A STEP is one batch of --batch (8) scenes.  The pipeline coalesces --merge consecutive batches into one PASS (default:
-4 batches = 32 scenes; every kernel of the path works scene by scene, so a scene's result does not depend on what
-shares its pass, and the larger launches fill the chip better: +12 % over one pass per batch, `--merge 1`).
+A STEP is one batch of --batch (8) scenes.  The pipeline coalesces --merge consecutive batches into one PASS (default at
+K = 20: 10 batches = 80 scenes; every kernel of the path works scene by scene, so a scene's result does not depend on what
+shares its pass, and the larger launches fill the chip better: +35 % over one pass per batch, `--merge 1`; +6 % over 32-scene
+passes at 2.5x their latency under load — `operating_points` keeps the smaller shapes in the line).
 
 Timing: the pipeline holds 20 passes (16 in their GEMM stage + 4 whose sampler stage runs ahead), i.e. 80 steps, so a
 sync-bracketed run of K steps is mostly pipeline fill + drain when K is small.  `value` is therefore measured
@@ -27,7 +28,7 @@ and after the stream.  Every pass leaves a timing event behind its last kernel; 
 device time at which every step <= s is complete (passes run on different streams and may finish out of order: this
 is what an in-order consumer sees).  A window runs from the delivery of step s to the delivery of step s + K — exactly
 K steps are delivered inside it — and `value` is K x batch over the MEAN of the windows starting on consecutive pass
-boundaries over >= 768 steps of the stream (a single window of K = 20 steps is 5 passes out of 16 in flight: +-30 %
+boundaries over >= 768 steps and >= 16 pipeline capacities of the stream (a single window of K = 20 steps is 5 passes out of 16 in flight: +-30 %
 noisy, and its median is quantised; the mean window is the steady-state time of K steps).  The sync-bracketed time of
 K steps on an empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the
 timed region every pass's last result is compared with ONE-BATCH eager passes over the same batches (`selfcheck`); a
@@ -69,7 +70,7 @@ sys.path.insert(0, ROOT)
 from de6d_amd.runtime import ScenePipeline, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd import synthetic  # noqa: E402
 from bench_legs import (MAIN_STREAMS, SAMPLER_STREAMS, coalesce_factor, compact_fill, index_kernel_rates,  # noqa: E402
-                        input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, selfcheck)
+                        input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, scenes_per_pass_target, selfcheck)
 
 
 def synth_points(seed0, b, n, tilt=False, scene='uniform'):
@@ -156,7 +157,7 @@ def orchestrate(args):
             ("configs[3] KITTI 3-class, batch 32 over 8 GPUs = 4 scenes per GPU per step",
              ['--cfg', 'kitti_models/det6d_3class.yaml', '--batch', '4', '--merge', '-1']),
             ("configs[4] 65536 points per scene, batch 64 over 8 GPUs = 8 scenes per GPU per step",
-             ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8']),
+             ['--cfg', 'synthetic_models/det6d_65536.yaml', '--points', '65536', '--batch', '8', '--merge', '-1']),
             ("configs[1] on ray-cast 64-ring LiDAR scenes (range-dependent density: realistic ball fill)", ['--scene', 'beam']),
             ("configs[2] on ray-cast 64-ring LiDAR scenes with a ramp", ['--scene', 'beam', '--tilt', '--cfg', 'slopedkitti_models/det6d_car.yaml']),
         ]
@@ -174,10 +175,12 @@ def orchestrate(args):
         # Operating points (round-4 review item 7): the same engine with fewer passes in flight — less throughput, a fraction
         # of the latency under load.  (main streams, sampler stages issued ahead): p50 / p99 of host issue -> in-order delivery.
         pts = {}
-        for streams, ahead in ((4, 2), (4, 4), (8, 4)):
-            r = child_rate(args, {}, ['--streams', str(streams), '--prefetch', str(ahead)])
-            pts["%d main streams, %d ahead" % (streams, ahead)] = {k: r.get(k) for k in ("scenes_per_s", "latency_under_load_ms", "selfcheck", "error") if k in r}
-        pts["%d main streams, %d ahead (value)" % (args.streams, args.prefetch)] = {
+        for scenes, streams, ahead in ((32, 4, 2), (32, 4, 4), (32, 16, 4)):
+            m_ = coalesce_factor(args.batch, args.steps, scenes)
+            r = child_rate(args, {}, ['--merge', str(m_), '--streams', str(streams), '--prefetch', str(ahead)])
+            pts["%d-scene passes, %d main streams, %d ahead" % (m_ * args.batch, streams, ahead)] = {
+                k: r.get(k) for k in ("scenes_per_s", "latency_under_load_ms", "selfcheck", "error") if k in r}
+        pts["%d-scene passes, %d main streams, %d ahead (value)" % (args.merge * args.batch, args.streams, args.prefetch)] = {
             "scenes_per_s": line["value"], "latency_under_load_ms": line.get("latency_under_load", {}).get("ms_p50_p99"), "selfcheck": line.get("selfcheck")}
         line["operating_points"] = pts
         line["config"]["operating_points_scenes_per_s_at_p50_ms"] = {
@@ -185,7 +188,8 @@ def orchestrate(args):
         # roofline.traffic measured in THIS run (two rocprofv3 --pmc child passes of this bench); the committed summary only as
         # a fallback, named as such
         if isinstance(line.get("roofline"), dict) and not args.no_roofline:
-            tr = measured_traffic(os.path.abspath(__file__), ['--cfg', args.cfg, '--points', str(args.points)])
+            tr = measured_traffic(os.path.abspath(__file__), ['--cfg', args.cfg, '--points', str(args.points)],
+                                  scenes_per_pass=args.batch * args.merge)
             if tr is not None:
                 line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = "measured in this run"
@@ -238,7 +242,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--merge', type=int, default=-1, help='consecutive batches coalesced into one pass (ScenePipeline merge); default: as many as make a pass of 32 scenes; 1 = one pass per batch')
+    ap.add_argument('--fill-pace-ms', type=float, default=0.0, help='space the GEMM-stage launches of the pipeline fill this far apart (ScenePipeline.run fill_interval)')
+    ap.add_argument('--dump-deliveries', default='', help='worker: write "step delivery_time_s" of every step of the stream to this file (scripts/r05/delivery_rate.py reads it)')
+    ap.add_argument('--merge', type=int, default=-1, help='consecutive batches coalesced into one pass (ScenePipeline merge); default: as many as make a pass of <= 80 scenes (<= 32 for scenes of more than 16384 points) and divide --steps; 1 = one pass per batch')
     ap.add_argument('--streams', type=int, default=-1, help='default 16 (4 for 65536-point scenes: the same throughput at a third of the latency under load); main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
     ap.add_argument('--prefetch', type=int, default=-1, help='groups whose sampler stage is issued ahead of the GEMM stage (default 4; 2 for scenes of more than 16384 points)')
     ap.add_argument('--sampler-streams', type=int, default=6)
@@ -257,11 +263,12 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of captured hipGraphs')
     ap.add_argument('--h2d', action='store_true', help='PCIe-inclusive variant: every step uploads its batch from pinned host memory (never the headline value)')
     args = ap.parse_args()
-    # pipeline shape: coalesced passes of 32 scenes by default (scripts/r02/gpu_batchsweep.sh, gpu_mergesweep.sh)
+    # pipeline shape: coalesced passes of up to 80 scenes by default (32 for scenes of more than 16384 points: bench_legs.
+    # scenes_per_pass_target; round 2 settled on 32, round 5 re-measured: scripts/r05/gpu_t14.sh .. gpu_t16.sh)
     if args.merge < 0:
-        # the largest number of batches per pass that keeps a pass <= 32 scenes and divides K (a window of K steps is then a
+        # the largest number of batches per pass that keeps a pass within that size and divides K (a window of K steps is then a
         # whole number of passes: exactly K steps are delivered inside it)
-        args.merge = 1 if (args.no_graph or args.group == 0) else coalesce_factor(args.batch, args.steps)
+        args.merge = 1 if (args.no_graph or args.group == 0) else coalesce_factor(args.batch, args.steps, scenes_per_pass_target(args.points))
     if args.group < 0:
         args.group = 4 if args.merge == 1 else 1
     # Pipeline depth by scene size: a pass of 65536-point scenes keeps the GEMM family busy 11x longer than one of 16384-point
@@ -354,7 +361,7 @@ def main():
         SAMPLER_STREAMS.extend(pipe.sampler_streams)
 
         def run(steps, on_done=None):
-            return pipe.run(steps, feed=host_batch, on_done=on_done)
+            return pipe.run(steps, feed=host_batch, on_done=on_done, fill_interval=args.fill_pace_ms * 1e-3)
         capacity, k = len(pipe.passes) * merge, pipe.k * merge      # in steps (batches)
     else:
         host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None
@@ -395,7 +402,10 @@ def main():
     preroll = (args.preroll if args.preroll >= 0 else 8) * capacity   # long enough for clocks / power to settle (~0.2 s)
     preroll += (-(preroll + args.warmup)) % k        # the windows start on group boundaries
     n_windows = args.windows if args.windows > 0 else max(17, -(-768 // k))   # the windows span >= 768 steps of the stream
-    n_windows = max(n_windows, -(-2 * capacity // k))    # ... and never less than two pipeline capacities (deliveries are lumpy)
+    # ... and never less than SIXTEEN pipeline capacities when the span is left to the bench: the passes in flight complete in
+    # lock-step bursts (a burst = one capacity), so a span of 4-5 bursts quantises the mean by +-4 % between runs of the same
+    # build (round 5, 80-scene passes: 16.3-17.6 k scenes/s from one configuration); 16 bursts bring that to ~1 %
+    n_windows = max(n_windows, -(-(16 if args.windows <= 0 else 2) * capacity // k))
     tail = capacity
     first = preroll + args.warmup - 1
     last = first + (n_windows - 1) * k + args.steps
@@ -445,6 +455,18 @@ def main():
     if elapsed_own <= 0.0:
         raise SystemExit("bench.py: the windows cover no time (stream too short for the pipeline): raise --windows or --steps")
     elapsed = elapsed_own
+    # two cross-checks of the window mean, printed beside it (neither is `value`): the least-squares slope of delivery time over
+    # step index across the same span (insensitive to where the span's two ends fall inside a burst of completions), and the
+    # whole stream on the host clock (pipeline fill, drain and the pre-roll included: a lower bound)
+    span = [s_ for s_ in range(first, last + 1) if s_ in stamps]
+    mean_s, mean_t = sum(span) / len(span), sum(stamps[s_] for s_ in span) / len(span)
+    slope = sum((s_ - mean_s) * (stamps[s_] - mean_t) for s_ in span) / sum((s_ - mean_s) ** 2 for s_ in span)
+    if args.dump_deliveries:
+        with open(args.dump_deliveries, 'w') as f:      # step index, in-order delivery time [s] since the stream started
+            f.write(''.join('%d %.6f\n' % (s_, stamps[s_]) for s_ in sorted(stamps)))
+    crosscheck = {"fit_scenes_per_s": round(world * b / slope, 1), "whole_stream_scenes_per_s": round(world * (last + 1 + tail) * b / t_stream, 1),
+                  "note": "fit = least-squares slope of in-order delivery time over step index across the windows' span; whole stream = "
+                          "all %d steps over the host clock between the two barriers (fill + drain inside); per-rank figures x ranks" % (last + 1 + tail)}
 
     # ---- cold: K steps on an EMPTY pipeline, synchronize on both sides (fill + drain inside) ----------------------------
     bracket()
@@ -507,7 +529,7 @@ def main():
                        "parallelism": "scene-sharded x%d, no collective" % world},
             "selfcheck": check,
             "ranks_seen": ranks_seen, "per_rank_scenes_per_s": per_rank,
-            "stream_total_s": round(t_stream, 4), "host_blocked_frac": round(host_wait / t_stream, 3),
+            "crosscheck": crosscheck, "stream_total_s": round(t_stream, 4), "host_blocked_frac": round(host_wait / t_stream, 3),
             "detections_in_window": dets[0],
             "cold": {"scenes_per_s": round(world * args.steps * b / cold, 2), "ms_per_step": round(cold / args.steps * 1e3, 4),
                      "note": "the same %d steps on an empty pipeline, barrier+synchronize on both sides: pipeline fill + drain included" % args.steps},

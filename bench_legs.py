@@ -323,7 +323,15 @@ def compact_fill(model, points, batch):
     return out
 
 
-def coalesce_factor(batch, steps, scenes_per_pass=32):
+#: scenes per coalesced pass the bench aims for, by scene size: 16384-point scenes 80 (round 5: 64-80 scenes per pass deliver 6-7 %
+#: more than 32 — 16 290 vs 15 320 scenes/s uniform, 6 960 vs 6 560 ray-cast, 17 900 vs 16 200 sloped — at 2.5x the latency
+#: under load: scripts/r05/gpu_t14.sh .. gpu_t16.sh; `operating_points` keeps the smaller shapes in the line), larger scenes 32
+#: (65536 points: 1 276 vs 1 285 scenes/s with 80, p50 374 vs 148 ms)
+def scenes_per_pass_target(points):
+    return 80 if points <= 16384 else 32
+
+
+def coalesce_factor(batch, steps, scenes_per_pass=80):
     """batches per pass: the largest d with d * batch <= scenes_per_pass that divides `steps` (a window of K steps is then a
     whole number of passes: exactly K steps are delivered inside it)"""
     return max(d for d in range(1, max(1, scenes_per_pass // max(1, batch)) + 1) if steps % d == 0)
@@ -350,10 +358,10 @@ def selfcheck(model, pipe, b):
     return bad, total
 
 
-def measured_traffic(bench_path, extra_args=(), passes=3, timeout=420):
+def measured_traffic(bench_path, extra_args=(), passes=3, timeout=420, scenes_per_pass=32):
     """HBM bytes per GEMM-family launch MEASURED in this run (round-4 review: the line used to quote the newest committed PMC
     summary): two child processes of this bench under `rocprofv3 --pmc` — FETCH_SIZE and WRITE_SIZE cannot share a pass
-    (MI355X_MICROARCH.md, rocprofv3 PMC slots) — each running `passes` eager 32-scene passes on one stream; bytes =
+    (MI355X_MICROARCH.md, rocprofv3 PMC slots) — each running `passes` eager passes of `scenes_per_pass` scenes on one stream; bytes =
     FETCH_SIZE x 2 (gfx950 tallies a 128-byte request of a 16-byte-per-lane read at 64 bytes) + WRITE_SIZE, both reported in
     KiB, summed over the family's dispatches of the profiled passes.  Returns None when rocprofv3 is not on the PATH or a pass
     fails (the caller then falls back to the committed summary and says so)."""
@@ -371,7 +379,7 @@ def measured_traffic(bench_path, extra_args=(), passes=3, timeout=420):
         d = tempfile.mkdtemp(prefix='det6d_pmc_')
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-                   sys.executable, bench_path, '--gpus', '1', '--steps', str(passes + 2), '--warmup', '2', '--batch', '32', '--streams', '1',
+                   sys.executable, bench_path, '--gpus', '1', '--steps', str(passes + 2), '--warmup', '2', '--batch', str(scenes_per_pass), '--streams', '1',
                    '--no-graph', '--cpu-scenes', '0', '--no-roofline', '--no-legs', '--worker', '--preroll', '0', '--windows', '1'] + list(extra_args)
             env = dict(os.environ, TMPDIR=os.environ.get('TMPDIR', '/tmp'))
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
@@ -396,6 +404,7 @@ def measured_traffic(bench_path, extra_args=(), passes=3, timeout=420):
     read, write = 2.0 * total['FETCH_SIZE'], total['WRITE_SIZE']
     return {"hbm_bytes_per_launch": round((read + write) / launches), "hbm_read_bytes_per_pass": round(read / n_pass),
             "hbm_write_bytes_per_pass": round(write / n_pass), "launches_per_pass": round(launches / n_pass, 2), "passes_profiled": n_pass,
-            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of this bench (eager 32-scene passes, one stream); "
+            "scenes_per_pass": scenes_per_pass,
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of this bench (eager passes of the timed region's size, one stream); "
                       "FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md"}
 

@@ -215,12 +215,17 @@ def test_scene_pipeline_step_accounting_with_coalesced_passes():
 
 
 def test_bench_coalesce_factor():
-    """bench.py: batches per pass = largest divisor of K that keeps a pass <= 32 scenes"""
+    """bench.py: batches per pass = largest divisor of K that keeps a pass within the target size (80 scenes for 16384-point
+    scenes, 32 for larger ones)"""
     import bench
-    assert bench.coalesce_factor(8, 20) == 4 and bench.coalesce_factor(8, 192) == 4
-    assert bench.coalesce_factor(8, 7) == 1 and bench.coalesce_factor(8, 6) == 3
-    assert bench.coalesce_factor(4, 20) == 5 and bench.coalesce_factor(4, 192) == 8
-    assert bench.coalesce_factor(32, 20) == 1 and bench.coalesce_factor(64, 20) == 1
+    from bench_legs import scenes_per_pass_target
+    assert scenes_per_pass_target(16384) == 80 and scenes_per_pass_target(65536) == 32
+    assert bench.coalesce_factor(8, 20, 32) == 4 and bench.coalesce_factor(8, 192, 32) == 4
+    assert bench.coalesce_factor(8, 7, 32) == 1 and bench.coalesce_factor(8, 6, 32) == 3
+    assert bench.coalesce_factor(4, 20, 32) == 5 and bench.coalesce_factor(4, 192, 32) == 8
+    assert bench.coalesce_factor(32, 20, 32) == 1 and bench.coalesce_factor(64, 20, 32) == 1
+    assert bench.coalesce_factor(8, 20) == 10 and bench.coalesce_factor(8, 192) == 8 and bench.coalesce_factor(8, 8) == 8
+    assert bench.coalesce_factor(4, 20) == 20 and bench.coalesce_factor(8, 7) == 7
 
 
 def test_mlp_rows_supported_query_mirrors_the_launch_checks():

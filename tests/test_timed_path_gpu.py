@@ -310,20 +310,21 @@ def test_bench_entry_point_checks_itself():
         assert key in d, key
     assert d['selfcheck'] == 'ok' and d['steps'] == 8 and d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['value'] > 0
     assert 'steady-state' in d['config']['timing'] and d['config']['points_per_scene'] == 16384
-    assert d['config']['batches_per_pass'] == 4 and d['config']['scenes_per_pass'] == 32      # 8 steps = 2 coalesced passes
+    assert d['config']['batches_per_pass'] == 8 and d['config']['scenes_per_pass'] == 64      # 8 steps = one coalesced pass
 
 
-@pytest.mark.parametrize("scene", ["beam", "uniform"])
-def test_coalesced_32_scene_passes_through_scene_pipeline_vs_oracle(oracle_ops, scene):
+@pytest.mark.parametrize("scene,merge", [("beam", 4), ("uniform", 4), ("uniform", 10), ("beam", 10)])
+def test_coalesced_32_scene_passes_through_scene_pipeline_vs_oracle(oracle_ops, scene, merge):
     """what bench.py's `value` (uniform scenes) and its `--scene beam` leg (ray-cast scenes, KITTI-like ball fill 0.3-0.9: the
-    GEMM-bound regime) time: batch 8 x 16384, four batches coalesced into 32-scene passes through ScenePipeline, every step
+    GEMM-bound regime) time: batch 8 x 16384, consecutive batches coalesced into 80-scene passes (merge 10: the bench's default
+    from round 5 on) and 32-scene passes (merge 4: rounds 2-4, the `operating_points` legs) through ScenePipeline, every step
     against the ORACLE's dense rows bit for bit — the 64-row mlp_rows tiles, the 2048-workgroup chain grids and (ray-cast) the
     full-ball class-32 tiles of the compact lists only occur at these row counts"""
     from de6d_amd.runtime import load_config, build_model, ScenePipeline
     from tests.util import beam_batch
     cfg = load_config('kitti_models/det6d_car.yaml')
     model = build_model(cfg, seed=1234, device='cuda')
-    b, n, merge = 8, 16384, 4
+    b, n = 8, 16384
     make = beam_batch if scene == "beam" else make_batch
     batches_np = [flat_points(make(4300 + 20 * j, b, n)) for j in range(merge)]
     batches = [torch.from_numpy(p).cuda() for p in batches_np]
