@@ -172,15 +172,25 @@ def orchestrate(args):
                 line["roofline"]["raycast"] = {"scenes_per_s": ray["scenes_per_s"], "frac": ray["roofline"]["frac"],
                                                "achieved": ray["roofline"]["achieved"],
                                                "algorithmic_gflop_per_pass": ray["roofline"]["algorithmic_gflop_per_pass"]}
-        # Operating points (round-4 review item 7): the same engine with fewer passes in flight — less throughput, a fraction
-        # of the latency under load.  (main streams, sampler stages issued ahead): p50 / p99 of host issue -> in-order delivery.
+        # Operating points (round-4 review item 7): the same engine at other points of its throughput / latency curve.
+        # `value` is the CLOSED loop (a new pass the moment a slot frees: every queue full, latency = queueing).  The PACED legs
+        # are an OPEN loop, the shape of a sensor: passes are issued on a fixed cadence (ScenePipeline.run headway) chosen as a
+        # fraction of `value`, so nothing queues and the latency is the processing time.  p50 / p99 of host issue -> delivery.
         pts = {}
-        for scenes, streams, ahead in ((32, 4, 2), (32, 4, 4), (32, 16, 4)):
+
+        def point(name, scenes, streams, ahead, pace):
             m_ = coalesce_factor(args.batch, args.steps, scenes)
-            r = child_rate(args, {}, ['--merge', str(m_), '--streams', str(streams), '--prefetch', str(ahead)])
-            pts["%d-scene passes, %d main streams, %d ahead" % (m_ * args.batch, streams, ahead)] = {
-                k: r.get(k) for k in ("scenes_per_s", "latency_under_load_ms", "selfcheck", "error") if k in r}
-        pts["%d-scene passes, %d main streams, %d ahead (value)" % (args.merge * args.batch, args.streams, args.prefetch)] = {
+            extra = ['--merge', str(m_), '--streams', str(streams), '--prefetch', str(ahead)]
+            if pace:
+                extra += ['--headway-ms', '%.3f' % (1e3 * m_ * args.batch / (pace * line["value"]))]
+            r = child_rate(args, {}, extra)
+            pts[name % (m_ * args.batch)] = {k: r.get(k) for k in ("scenes_per_s", "latency_under_load_ms", "selfcheck", "error") if k in r}
+            if pace:
+                pts[name % (m_ * args.batch)]["headway_ms"] = float(extra[-1])
+        point("%d-scene passes, 16 main streams, 4 ahead, closed loop", 32, 16, 4, 0.0)
+        point("%d-scene passes, 16 main streams, 2 ahead, paced at 0.93 x value", 32, 16, 2, 0.93)
+        point("%d-scene passes, 16 main streams, 2 ahead, paced at 0.97 x value", 80, 16, 2, 0.97)
+        pts["%d-scene passes, %d main streams, %d ahead, closed loop (value)" % (args.merge * args.batch, args.streams, args.prefetch)] = {
             "scenes_per_s": line["value"], "latency_under_load_ms": line.get("latency_under_load", {}).get("ms_p50_p99"), "selfcheck": line.get("selfcheck")}
         line["operating_points"] = pts
         line["config"]["operating_points_scenes_per_s_at_p50_ms"] = {
@@ -242,7 +252,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=48)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step')
     ap.add_argument('--points', type=int, default=16384)
-    ap.add_argument('--fill-pace-ms', type=float, default=0.0, help='space the GEMM-stage launches of the pipeline fill this far apart (ScenePipeline.run fill_interval)')
+    ap.add_argument('--headway-ms', type=float, default=0.0, help='keep consecutive GEMM-stage launches at least this far apart (ScenePipeline.run headway)')
     ap.add_argument('--dump-deliveries', default='', help='worker: write "step delivery_time_s" of every step of the stream to this file (scripts/r05/delivery_rate.py reads it)')
     ap.add_argument('--merge', type=int, default=-1, help='consecutive batches coalesced into one pass (ScenePipeline merge); default: as many as make a pass of <= 80 scenes (<= 32 for scenes of more than 16384 points) and divide --steps; 1 = one pass per batch')
     ap.add_argument('--streams', type=int, default=-1, help='default 16 (4 for 65536-point scenes: the same throughput at a third of the latency under load); main streams = passes in their GEMM stage; main + sampler streams must stay below GPU_MAX_HW_QUEUES (12 -> 8560, 16 -> 9680, 18 -> 7720 scenes/s)')
@@ -361,7 +371,7 @@ def main():
         SAMPLER_STREAMS.extend(pipe.sampler_streams)
 
         def run(steps, on_done=None):
-            return pipe.run(steps, feed=host_batch, on_done=on_done, fill_interval=args.fill_pace_ms * 1e-3)
+            return pipe.run(steps, feed=host_batch, on_done=on_done, headway=args.headway_ms * 1e-3)
         capacity, k = len(pipe.passes) * merge, pipe.k * merge      # in steps (batches)
     else:
         host_batch = torch.from_numpy(pts_np).pin_memory() if args.h2d else None

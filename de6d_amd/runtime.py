@@ -643,14 +643,14 @@ class ScenePipeline(object):
             r.finalize()
         torch.cuda.synchronize()
 
-    def run(self, steps, feed=None, on_done=None, fill_interval=0.0):
+    def run(self, steps, feed=None, on_done=None, headway=0.0):
         """`steps` batches through the pipeline (ceil(steps / merge) passes; the last pass of a stream whose length is not a
         multiple of `merge` runs full and reports its leading batches only); `feed` (host tensor one pass long, list of
         the batches of a pass, or callable(pass)) supplies the input of a pass whose static buffer is not resident already;
         on_done(step, pass, pred_dicts of that batch) is called in step order as passes are finalised.  Returns the number
-        of steps finalised (== steps).  `fill_interval` [s] > 0 spaces the GEMM-stage launches of the first `n_groups` passes
-        (the pipeline fill) at least that far apart, so that the passes in flight sit at different depths of the network
-        instead of marching through it in lock-step; no effect on results."""
+        of steps finalised (== steps).  `headway` [s] > 0 keeps consecutive GEMM-stage launches at least that far apart
+        (headway control: passes that retire together are not re-issued together, so the passes in flight sit at different
+        depths of the network instead of marching through it in lock-step); no effect on results."""
         k, n_groups, prefetch, merge, sb = self.k, self.n_groups, self.prefetch, self.merge, self.step_scenes
         t_next = time.perf_counter()
         counts, left = [], (steps + merge - 1) // merge
@@ -676,10 +676,10 @@ class ScenePipeline(object):
                 finish(inflight.pop(0))
             if g + prefetch < len(counts):
                 self.groups[(g + prefetch) % n_groups].launch_front(feed, counts[g + prefetch])
-            if fill_interval > 0.0 and g < n_groups:
+            if headway > 0.0:
                 while time.perf_counter() < t_next:
-                    time.sleep(1e-4)
-                t_next = time.perf_counter() + fill_interval
+                    time.sleep(5e-5)
+                t_next = time.perf_counter() + headway
             inflight.append(self.groups[g % n_groups].launch_rest())
         for active in inflight:
             finish(active)

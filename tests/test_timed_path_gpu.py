@@ -334,7 +334,8 @@ def test_coalesced_32_scene_passes_through_scene_pipeline_vs_oracle(oracle_ops, 
 
     def on_done(step, r, preds):
         got[step] = [{k: v.clone() for k, v in p.items()} for p in preds]
-    assert pipe.run(2 * merge, on_done=on_done) == 2 * merge
+    # the 32-scene cases run PACED (ScenePipeline.run headway, the bench's open-loop operating points): same results
+    assert pipe.run(2 * merge, on_done=on_done, headway=2e-3 if merge == 4 else 0.0) == 2 * merge
     torch.cuda.synchronize()
     for j in range(merge):
         ref = oracle_of(cfg, model, batches_np[j], b)
