@@ -17,8 +17,8 @@ region.
 
 A STEP is one batch of --batch (8) scenes.  The pipeline coalesces --merge consecutive batches into one PASS (default at
 K = 20: 10 batches = 80 scenes; every kernel of the path works scene by scene, so a scene's result does not depend on what
-shares its pass, and the larger launches fill the chip better: +35 % over one pass per batch, `--merge 1`; +6 % over 32-scene
-passes at 2.5x their latency under load — `operating_points` keeps the smaller shapes in the line).
+shares its pass, and the larger launches fill the chip better: +23 % over one pass per batch, `--merge 1`; +2.6 % over 32-scene
+passes at 2.5x their latency under load — `operating_points` keeps the 32-scene shape and the PACED (open-loop) points in the line).
 
 Timing: the pipeline holds 20 passes (16 in their GEMM stage + 4 whose sampler stage runs ahead), i.e. 80 steps, so a
 sync-bracketed run of K steps is mostly pipeline fill + drain when K is small.  `value` is therefore measured
@@ -28,8 +28,12 @@ and after the stream.  Every pass leaves a timing event behind its last kernel; 
 device time at which every step <= s is complete (passes run on different streams and may finish out of order: this
 is what an in-order consumer sees).  A window runs from the delivery of step s to the delivery of step s + K — exactly
 K steps are delivered inside it — and `value` is K x batch over the MEAN of the windows starting on consecutive pass
-boundaries over >= 768 steps and >= 16 pipeline capacities of the stream (a single window of K = 20 steps is 5 passes out of 16 in flight: +-30 %
-noisy, and its median is quantised; the mean window is the steady-state time of K steps).  The sync-bracketed time of
+boundaries over >= 768 steps and >= 16 pipeline capacities of the stream (a single window of K = 20 steps is 2 passes out
+of 16 in flight: +-30 % noisy, and its median is quantised; the mean window is the steady-state time of K steps).  The passes in
+flight complete in lock-step bursts, so the mean of windows over a SHORT span depends on where the span's two ends fall inside a
+burst: rounds 2-4 spanned 768 steps (~10 bursts) and read ~5 % high (profiles/r05_span_bias_r04_vs_r05.txt).  `crosscheck`
+prints two independent rates beside `value`: the least-squares delivery rate over the same span and the whole stream (fill and
+drain included) on the host clock.  The sync-bracketed time of
 K steps on an empty pipeline (`cold`) and the latency of one batch (`latency`) are printed beside it.  After the
 timed region every pass's last result is compared with ONE-BATCH eager passes over the same batches (`selfcheck`); a
 mismatch exits non-zero.
@@ -526,6 +530,9 @@ def main():
                                  "(exactly %d steps delivered inside; delivered = every step up to it complete on the device); "
                                  "value = mean of %d windows starting on consecutive "
                                  "group boundaries" % (last + 1 + tail, preroll, args.warmup, tail, args.steps, args.steps, n_windows),
+                       "span_note": "from round 5 on the windows span >= 16 pipeline capacities; rounds 2-4 spanned 768 steps (~10 lock-step "
+                                    "completion bursts) and read ~5 % high: the round-4 build gives 14 544 scenes/s on that span and 13 806 "
+                                    "on this one (profiles/r05_span_bias_r04_vs_r05.txt); `crosscheck` carries two independent rates",
                        "preroll_steps": preroll, "tail_steps": tail, "windows": n_windows,
                        "window_ms_min_median_max": [round(windows[0] * 1e3, 3), round(window_median * 1e3, 3), round(windows[-1] * 1e3, 3)],
                        "window_ms_mean": round(elapsed_own * 1e3, 3),

@@ -41,6 +41,8 @@ for tag in ('z', 'beam', '65536'):
               round(d.get('hbm_bytes_per_launch', 0) * d.get('launches_per_step', 0) / max(1, d.get('scenes_per_step', 1)) / 1e6, 2))
         tot = {k: v.get('SQ_INSTS_VALU') for k, v in s.items() if isinstance(v, dict) and 'SQ_INSTS_VALU' in v}
         print('   vector instructions per pass (incl. MFMA) by family:', {k: round(v / 1e6, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
+cp('pmc_r05z_z80/kernel_stats.csv', 'r05_z80_kernel_stats.csv')
+cp('pmc_r05z_z80/launches_of_one_pass.txt', 'r05_z80_launches_of_one_pass.txt')
 cp('r05_pipe_pmc/pipeline_pmc_summary.json', 'r05_pipeline_pmc_summary.json')
 cp('r05_pipe_pmc/bench_under_profiler.json', 'r05_pipeline_pmc_bench_under_profiler.json')
 line = first_json_line(os.path.join(G, 'r05_final', 'bench_20.log'))

@@ -3,3 +3,5 @@ sfx=${1:-z}
 bash scripts/r05/gpu_pmc.sh r05${sfx}_z
 bash scripts/r05/gpu_pmc.sh r05${sfx}_beam --scene beam
 BATCH=8 STEPS=4 bash scripts/r05/gpu_pmc.sh r05${sfx}_65536 --cfg synthetic_models/det6d_65536.yaml --points 65536
+# per-kernel stats of the 80-scene pass the timed region issues by default (bench.py's roofline.avg_launch_us is taken on these launches)
+NOPMC=1 BATCH=80 STEPS=5 bash scripts/r05/gpu_pmc.sh r05${sfx}_z80

@@ -37,7 +37,8 @@ def family(name):
 
 # Only the STEADY-STATE part of the run is summed: the dispatches between the 30th and the 70th percentile of the dispatch
 # sequence lie inside the continuous stream of 32-scene passes (the prime, the cold run, the one-batch latency legs and the
-# eager self-check passes are at the ends), so "per pass" below is per 32-scene pass of the timed region.
+# eager self-check passes are at the ends), so "per pass" below is per pass of the timed region
+# (`scenes_per_pass` of the bench line; `whole_run_per_32_scenes` rescales to the 32-scene pass of rounds 2-4).
 rows = []
 for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -81,6 +82,9 @@ res['whole_run'] = {
     'valu_wave_insts_per_pass_other_kernels': valu_rest / passes,
     'waves_per_pass': tot.get('SQ_WAVES', 0.0) / passes,
 }
+# the default pass is 80 scenes from the second half of round 5 on; rounds 4-5 quote these figures per 32 scenes
+spp = res.get('scenes_per_pass') or 32
+res['whole_run_per_32_scenes'] = {k: v * 32.0 / spp for k, v in res['whole_run'].items() if isinstance(v, float) and 'frac' not in k}
 # the timed region's own clock: with the un-profiled pipeline delivering a pass every T seconds, the steady-state chip-level
 # matrix-busy fraction is (busy cycles per pass per SIMD) / (T x shader clock)
 res['how_to_price'] = ("steady-state matrix-pipe busy fraction = mfma_busy_cycles_per_pass_per_simd / (seconds per pass of the UN-profiled "
