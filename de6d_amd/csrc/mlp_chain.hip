@@ -846,7 +846,7 @@ DET6D_API int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *
   // group alone / with the chip full: 768 workgroups 137 / 65 us, 1024: 115 / 64, 2048: 97 / 65, 4096: 87 / 70; ray-cast
   // scenes 578 / 205, 507 / 205, 366 / 201, 299 / 206)
   int blocks = det6d_divup(ntiles, 4);
-  const int cap = 2048;
+  static const int cap = det6d_env_int("DET6D_CHAIN_BLOCKS", 2048);   // experiments build only
   if (blocks > cap) blocks = cap;
   if (c1 == 16)
     hipLaunchKernelGGL((mlp_chain_reg_kernel<16, 16, 32, 32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);

@@ -282,7 +282,15 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
     attr_bytes = lds_bytes;
   }
   int blocks = (rows + 32 * rb - 1) / (32 * rb);
-  if (blocks > 1024) blocks = 1024;      // (one workgroup per tile, up to 8192, measured no faster: 62 vs 61 us on 4096 tiles)
+  // persistent walk over the tiles by as many workgroups as the chip HOLDS at a time (LDS: 3 per CU for the SA stacks; 128
+  // registers: at most 4): a grid of 1024 on 768 slots ran its last 256 workgroups on a third of the chip (80-scene passes,
+  // SA1's stack: 768: 132 us, 1024: 153, 1536: 134, 2048: 139, 512: 161; scripts/r05/gpu_t29.sh).  DET6D_ROWS_BLOCKS:
+  // experiments build only.
+  int per_cu = (int)((160 * 1024) / lds_bytes);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  static const int blocks_env = det6d_env_int("DET6D_ROWS_BLOCKS", 0);
+  const int blocks_cap = blocks_env > 0 ? blocks_env : 256 * per_cu / nchains;     // the grid is (blocks, chains)
+  if (blocks > blocks_cap) blocks = blocks_cap;
   if (g.kchunk < g.k0)
     hipLaunchKernelGGL((mlp_rows_kernel<true, 1>), dim3(blocks, nchains), dim3(256), lds_bytes, (hipStream_t)stream, g);
   else if (rb == 2)

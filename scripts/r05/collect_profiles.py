@@ -49,7 +49,7 @@ line = first_json_line(os.path.join(G, 'r05_final', 'bench_20.log'))
 if line:
     json.dump(line, open(os.path.join(P, 'r05_z_bench.json'), 'w'), indent=1)
     print('copied r05_z_bench.json')
-for sc in ('uniform', 'beam', '65536'):
+for sc in ('uniform', 'beam', '65536', 'paced'):
     cp('r05_pipe_%s/pipeline_kernel_stats.csv' % sc, 'r05_%s_pipeline_kernel_stats.csv' % sc)
     cp('r05_pipe_%s/trace_summary.txt' % sc, 'r05_%s_pipeline_trace_summary.txt' % sc)
     cp('r05_pipe_%s/trace_overlap.txt' % sc, 'r05_%s_pipeline_trace_overlap.txt' % sc)

@@ -39,12 +39,18 @@ def family(name):
 # sequence lie inside the continuous stream of 32-scene passes (the prime, the cold run, the one-batch latency legs and the
 # eager self-check passes are at the ends), so "per pass" below is per pass of the timed region
 # (`scenes_per_pass` of the bench line; `whole_run_per_32_scenes` rescales to the 32-scene pass of rounds 2-4).
-rows = []
+rows, packs = [], {}
 for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r.get('Dispatch_Id') or 0), r.get('Kernel_Name', ''), r['Counter_Name'], float(r['Counter_Value'])))
+        if 'pack_points_kernel' in r.get('Kernel_Name', ''):
+            packs[rows[-1][0]] = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
 ids = sorted({r[0] for r in rows})
 lo_id, hi_id = ids[int(0.30 * len(ids))], ids[int(0.70 * len(ids))]
+if packs:       # second half of round 5: the slice is cut on the FULL-SIZE passes (largest pack_points grid = the stream's passes),
+    full = max(packs.values())      # 25th to 75th percentile: with 80-scene passes the eager 8-scene self-check passes at the end of
+    fs = sorted(i for i, g in packs.items() if g == full)   # the run are a third of all dispatches and reached into the 30-70 % slice
+    lo_id, hi_id = fs[len(fs) // 4], fs[3 * len(fs) // 4]
 sums = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for d_id, name, ctr, val in rows:

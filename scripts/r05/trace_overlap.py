@@ -14,8 +14,17 @@ for r in rows:
     ev.append((s, e, r['Kernel_Name'], r.get('Queue_Id', '?')))
 ev.sort()
 t0, t1 = ev[0][0], max(e for _, e, _, _ in ev)
-# steady window: the middle 50 % of the launches of the trace
-lo, hi = ev[len(ev) // 4][0], ev[3 * len(ev) // 4][0]
+# steady window: between the 25th and the 75th percentile of the FULL-SIZE passes of the trace (a pass starts with
+# pack_points_kernel; the stream's passes have the largest grid — the one-batch latency legs and the eager self-check passes at
+# the end of the run pack 8 scenes; with 80-scene passes those are a third of all launches, so "the middle half of the launches"
+# (the first form of this script) reached into them)
+packs = [(int(r['Start_Timestamp']), int(r.get('Grid_Size_X') or r.get('Grid_Size') or 0)) for r in rows if 'pack_points_kernel' in r['Kernel_Name']]
+if packs:
+    full = max(g for _, g in packs)
+    starts = sorted(t for t, g in packs if g == full)
+    lo, hi = starts[len(starts) // 4], starts[3 * len(starts) // 4]
+else:
+    lo, hi = ev[len(ev) // 4][0], ev[3 * len(ev) // 4][0]
 pts = []
 for s, e, name, q in ev:
     if e <= lo or s >= hi:
