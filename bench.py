@@ -73,7 +73,7 @@ sys.path.insert(0, ROOT)
 
 from de6d_amd.runtime import ScenePipeline, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd import synthetic  # noqa: E402
-from bench_legs import (MAIN_STREAMS, SAMPLER_STREAMS, coalesce_factor, compact_fill, index_kernel_rates,  # noqa: E402
+from bench_legs import (span_windows, window_times, delivery_fit, MAIN_STREAMS, SAMPLER_STREAMS, coalesce_factor, compact_fill, index_kernel_rates,  # noqa: E402
                         input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, scenes_per_pass_target, selfcheck)
 
 
@@ -415,11 +415,8 @@ def main():
     # boundaries, and the MEAN window is the timed region.
     preroll = (args.preroll if args.preroll >= 0 else 8) * capacity   # long enough for clocks / power to settle (~0.2 s)
     preroll += (-(preroll + args.warmup)) % k        # the windows start on group boundaries
-    n_windows = args.windows if args.windows > 0 else max(17, -(-768 // k))   # the windows span >= 768 steps of the stream
-    # ... and never less than SIXTEEN pipeline capacities when the span is left to the bench: the passes in flight complete in
-    # lock-step bursts (a burst = one capacity), so a span of 4-5 bursts quantises the mean by +-4 % between runs of the same
-    # build (round 5, 80-scene passes: 16.3-17.6 k scenes/s from one configuration); 16 bursts bring that to ~1 %
-    n_windows = max(n_windows, -(-(16 if args.windows <= 0 else 2) * capacity // k))
+    # the windows span >= 768 steps and >= 16 pipeline capacities of the stream (bench_legs.span_windows: why 16)
+    n_windows = span_windows(capacity, k, args.windows)
     tail = capacity
     first = preroll + args.warmup - 1
     last = first + (n_windows - 1) * k + args.steps
@@ -463,7 +460,7 @@ def main():
                                       "in-order delivery of the step on the device clock, with the pipeline full" % args.prefetch}
     else:
         latency_under_load = None
-    windows = sorted(stamps[first + j * k + args.steps] - stamps[first + j * k] for j in range(n_windows))
+    windows = window_times(stamps, first, k, args.steps, n_windows)
     window_median = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
     elapsed_own = sum(windows) / len(windows)
     if elapsed_own <= 0.0:
@@ -472,9 +469,7 @@ def main():
     # two cross-checks of the window mean, printed beside it (neither is `value`): the least-squares slope of delivery time over
     # step index across the same span (insensitive to where the span's two ends fall inside a burst of completions), and the
     # whole stream on the host clock (pipeline fill, drain and the pre-roll included: a lower bound)
-    span = [s_ for s_ in range(first, last + 1) if s_ in stamps]
-    mean_s, mean_t = sum(span) / len(span), sum(stamps[s_] for s_ in span) / len(span)
-    slope = sum((s_ - mean_s) * (stamps[s_] - mean_t) for s_ in span) / sum((s_ - mean_s) ** 2 for s_ in span)
+    slope = delivery_fit(stamps, first, last)
     if args.dump_deliveries:
         with open(args.dump_deliveries, 'w') as f:      # step index, in-order delivery time [s] since the stream started
             f.write(''.join('%d %.6f\n' % (s_, stamps[s_]) for s_ in sorted(stamps)))

@@ -337,6 +337,29 @@ def coalesce_factor(batch, steps, scenes_per_pass=80):
     return max(d for d in range(1, max(1, scenes_per_pass // max(1, batch)) + 1) if steps % d == 0)
 
 
+def span_windows(capacity, k, requested=-1, floor_steps=768):
+    """number of K-step windows (one per pass boundary, k steps apart) in the timed span.  Left to the bench (requested <= 0):
+    >= floor_steps steps AND >= 16 pipeline capacities — the passes in flight complete in lock-step bursts, one burst per
+    capacity, and the mean of windows over a span of few bursts depends on where its two ends fall inside a burst (rounds 2-4:
+    768 steps = 5-10 bursts read ~5 % high; tests/test_host_logic.py reproduces it on a synthetic delivery series).  An explicit
+    request is honoured down to two capacities."""
+    n = requested if requested > 0 else max(17, -(-floor_steps // k))
+    return max(n, -(-(16 if requested <= 0 else 2) * capacity // k))
+
+
+def window_times(stamps, first, k, steps, n_windows):
+    """sorted durations of the windows "delivery of step first + j k -> delivery of step first + j k + steps", j < n_windows"""
+    return sorted(stamps[first + j * k + steps] - stamps[first + j * k] for j in range(n_windows))
+
+
+def delivery_fit(stamps, first, last):
+    """least-squares slope [s per step] of delivery time over step index across [first, last]: a rate estimate that does not
+    depend on where the span's two ends fall inside a burst of completions"""
+    span = [s_ for s_ in range(first, last + 1) if s_ in stamps]
+    mean_s, mean_t = sum(span) / len(span), sum(stamps[s_] for s_ in span) / len(span)
+    return sum((s_ - mean_s) * (stamps[s_] - mean_t) for s_ in span) / sum((s_ - mean_s) ** 2 for s_ in span)
+
+
 def selfcheck(model, pipe, b):
     """every pass's LAST finalised result against an eager pass over the same batch, bit for bit (the captured segments,
     the grouped first sampler and the stream choreography must not change a single detection)"""

@@ -228,6 +228,40 @@ def test_bench_coalesce_factor():
     assert bench.coalesce_factor(4, 20) == 20 and bench.coalesce_factor(8, 7) == 7
 
 
+def test_timed_span_is_long_enough_for_lock_step_deliveries():
+    """bench.py's `value` is K x batch over the MEAN of K-step windows starting on consecutive pass boundaries; that mean
+    telescopes to (delivery of the span's last passes - delivery of its first) / passes.  With the passes in flight completing
+    in lock-step (16 at the same instant, then nothing for a burst period) a span of few bursts that starts right after a
+    burst — as the pre-roll of a whole number of capacities makes it — reads high: rounds 2-4 spanned 768 steps and quoted
+    ~5 % too much (profiles/r05_span_bias_r04_vs_r05.txt).  bench_legs.span_windows now spans >= 16 capacities, and the
+    least-squares fit printed beside it does not care where the ends fall."""
+    from bench_legs import span_windows, window_times, delivery_fit
+    merge, in_flight, ahead, K = 10, 16, 4, 20              # 80-scene passes: 16 in the GEMM stage + 4 sampler stages ahead
+    capacity, k = (in_flight + ahead) * merge, merge
+    period = 5.39e-3                                         # true seconds per pass (14 850 scenes/s at 80 scenes per pass)
+    burst = in_flight * period
+
+    def stamps_of(n_steps):                                  # every pass of a burst is delivered when the burst completes
+        return {s: (s // merge // in_flight + 1) * burst for s in range(n_steps)}
+
+    def value(n_windows, first):
+        stamps = stamps_of(first + n_windows * k + K + capacity)
+        w = window_times(stamps, first, k, K, n_windows)
+        return K / (sum(w) / len(w)), 1.0 / delivery_fit(stamps, first, first + (n_windows - 1) * k + K)
+    true = 1.0 / (period / merge)                            # steps per second
+    preroll = 8 * capacity + (-(8 * capacity + 5)) % k       # bench.py: pre-roll of 8 capacities, the windows start on a pass boundary
+    first = preroll + 5 - 1                                  # ... after 5 warmup steps
+    short, short_fit = value(max(17, -(-768 // k)), first)   # rounds 2-4: 77 windows = 4.8 bursts
+    assert short / true > 1.10                               # ... reads > 10 % high on ideal lock-step (measured on the chip: ~5-14 %)
+    assert abs(short_fit / true - 1.0) < 0.06                # the fit over the same short span is already within a few per cent
+    n = span_windows(capacity, k)
+    assert n * k >= 16 * capacity and n >= -(-768 // k)
+    long_, long_fit = value(n, first)
+    assert abs(long_ / true - 1.0) < 0.045 and abs(long_fit / true - 1.0) < 0.01
+    assert span_windows(capacity, k, requested=3) == -(-2 * capacity // k)      # an explicit request: at least two capacities
+    assert span_windows(20, 1) == 768                        # one pass per batch: 768 steps are already 38 capacities
+
+
 def test_mlp_rows_supported_query_mirrors_the_launch_checks():
     """det6d_mlp_rows_supported (host logic of csrc/mlp_rows.hip: chain structure, widths, the 160 KB of LDS a 32-row tile's
     two activation buffers may take) decides fused.mlp_rows_eligible: a stack that does not fit is routed through one
