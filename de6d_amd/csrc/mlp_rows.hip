@@ -199,6 +199,132 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   }
 }
 
+// ---- the SA1-shaped stack [K0 -> K1 -> K2 -> n <= 32] over MANY rows (the first level's aggregation + confidence chain:
+// 4096 centres per scene), weights RESIDENT in registers --------------------------------------------------------------------
+// Round 5 (scripts/r05/whatif_twice.py): the pass period pays for 97 % of this launch's stand-alone time, and the general kernel
+// above spends it waiting, not computing — per 64-row tile 288 MFMAs (1.9 us of a CU's matrix pipes) inside ~20 us of input
+// load -> barrier -> [weight fragments from L2 -> K loop -> barrier] x 3.  The whole stack's weights are 9 216 floats: every
+// wave keeps the B fragments of ITS work items in registers for the life of the (persistent) workgroup — layer 0: K0 / 2
+// registers for (row block = wave & 1, column tile = wave >> 1); waves 2, 3 the K1 / 2 of layer 1, waves 0, 1 the K2 / 2 of
+// layer 2 — so a tile touches memory only for its input rows (prefetched into registers one tile ahead, double-buffered in
+// LDS: three barriers per tile, none at its end) and its outputs.  Same MFMA sequence per output element as the general
+// kernel (ascending k, + shift, activation): bit-identical.
+// one work item of a layer: 32 rows (xa: this lane's row and k parity in LDS) x the wave's resident B fragments, NBLK blocks of
+// 16 k-steps in ascending k
+template <int NBLK, int NB>
+__device__ __forceinline__ f32x16 rows_item(const float *xa, const float (&b)[NB]) {
+  static_assert(16 * NBLK <= NB, "the fragment array holds the layer");
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    float a[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = xa[32 * blk + 2 * u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[16 * blk + u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(256) void mlp_rows_resident_kernel(const RowsArgs g) {
+  constexpr int TR = 64, LDA = K0 + 1, LDB = K1 + 1, NV = K0 / 16;    // NV float4 per thread and input row (4 threads per row)
+  static_assert(K0 % 32 == 0 && K1 % 32 == 0 && K2 % 32 == 0 && K2 <= K1 && K1 <= 64 && K2 <= K0, "SA1-shaped stacks only");
+  extern __shared__ float lds[];
+  float *XA0 = lds, *XA1 = lds + TR * LDA, *XB = lds + 2 * TR * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const det6d_rows_layer &L0 = g.layers[0][0], &L1 = g.layers[0][1], &L2 = g.layers[0][2];
+  const int rb = wave & 1, j0 = wave >> 1;
+  const bool second = wave >= 2;                  // waves 2, 3 run layer 1, waves 0, 1 layer 2 (row block = wave & 1 in both)
+  const det6d_rows_layer &LX = second ? L1 : L2;
+  float b0[K0 / 2], bx[K1 / 2];
+  {
+    const __amdgpu_buffer_rsrc_t srd0 =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(L0.w + (size_t)L0.wrow0 * L0.ldw), 0, (unsigned)((size_t)L0.k * L0.ldw * 4), 0x00020000);
+    const uint32_t voff0 = (uint32_t)(kh * L0.ldw + 32 * j0 + l31) * 4u;
+#pragma unroll
+    for (int u = 0; u < K0 / 2; ++u) b0[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd0, voff0, 2 * u * L0.ldw * 4, 0));
+    const __amdgpu_buffer_rsrc_t srdx =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(LX.w + (size_t)LX.wrow0 * LX.ldw), 0, (unsigned)((size_t)LX.k * LX.ldw * 4), 0x00020000);
+    const uint32_t voffx = (uint32_t)(kh * LX.ldw + l31) * 4u;
+    const int kx = second ? K1 / 2 : K2 / 2;
+#pragma unroll
+    for (int u = 0; u < K1 / 2; ++u)
+      bx[u] = u < kx ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdx, voffx, 2 * u * LX.ldw * 4, 0)) : 0.f;
+  }
+  const int col0 = 32 * j0 + l31;
+  const bool cok0 = col0 < L0.n, cokx = l31 < LX.n;
+  const float sh0 = (cok0 && L0.shift) ? L0.shift[col0] : 0.f;
+  const float shx = (cokx && LX.shift) ? LX.shift[l31] : 0.f;
+  const int ntiles = (g.rows + TR - 1) / TR;
+  const int lrow = tid >> 2, lq = tid & 3;
+  f32x4r nxt[NV];
+  auto gload = [&](const int tile) {
+    const int r = tile * TR + lrow;
+    const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0 + 4 * lq;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      nxt[i] = *reinterpret_cast<const f32x4r *>(src + 16 * i);
+      if (r >= g.rows) nxt[i] = f32x4r{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) gload(tile);
+  for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    float *XA = buf ? XA1 : XA0;
+    {
+      float *dst = XA + lrow * LDA + 4 * lq;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[16 * i + e] = nxt[i][e];
+    }
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);     // the next tile's rows: in flight during this tile's layers
+    __syncthreads();                                // the input tile is complete
+    {
+      const f32x16 acc = rows_item<K0 / 32>(XA + (32 * rb + l31) * LDA + kh, b0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[e] + sh0;
+        if (L0.act == 1) v = d6_relu(v);
+        if (cok0) XB[row * LDB + col0] = v;
+        const int r = tile * TR + row;
+        if (L0.out && cok0 && r < g.rows) L0.out[(size_t)r * L0.ldo + L0.ocol0 + col0] = v;
+      }
+    }
+    __syncthreads();                                // layer 0's output is complete (and the input tile is dead)
+    if (second) {
+      const f32x16 acc = rows_item<K1 / 32>(XB + (32 * rb + l31) * LDB + kh, bx);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[e] + shx;
+        if (L1.act == 1) v = d6_relu(v);
+        if (cokx) XA[row * LDA + l31] = v;
+        const int r = tile * TR + row;
+        if (L1.out && cokx && r < g.rows) L1.out[(size_t)r * L1.ldo + L1.ocol0 + l31] = v;
+      }
+    }
+    __syncthreads();                                // layer 1's output is complete
+    if (!second) {
+      const f32x16 acc = rows_item<K2 / 32>(XA + (32 * rb + l31) * LDA + kh, bx);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[e] + shx;
+        if (L2.act == 1) v = d6_relu(v);
+        const int r = tile * TR + row;
+        if (L2.out && cokx && r < g.rows) L2.out[(size_t)r * L2.ldo + L2.ocol0 + l31] = v;
+      }
+    }
+    // no barrier here: the next tile's input goes to the OTHER input buffer, and XB is rewritten only behind the next tile's
+    // first barrier, which waves 0, 1 reach after this layer
+  }
+}
+
 }  // namespace
 
 // Validates a stack description and derives the LDS plan: k0 (input width), wa / wb (row widths of the two activation
@@ -265,6 +391,17 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   if (xcol0 + k0 > ldx) return DET6D_EINVAL;
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
+  // the first level's stack ([96 -> 64 -> 32 -> 1] over 4096 centres per scene): weights resident in registers
+  static const int resident_env = det6d_env_int("DET6D_ROWS_RESIDENT", 1);      // experiments build: 0 = the general kernel
+  if (resident_env && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && layers[0].k == 96 &&
+      layers[0].n == 64 && layers[1].n == 32 && layers[2].n <= 32 && layers[0].ldw >= 64 && layers[1].ldw >= 32) {
+    constexpr size_t lds_resident = sizeof(float) * (2 * 64 * 97 + 64 * 65);
+    DET6D_MAX_DYNAMIC_LDS((mlp_rows_resident_kernel<96, 64, 32>), lds_resident);
+    int blocks = (rows + 63) / 64;
+    if (blocks > 512) blocks = 512;                  // two workgroups per CU (66 KB of LDS each), persistent over the tiles
+    hipLaunchKernelGGL((mlp_rows_resident_kernel<96, 64, 32>), dim3(blocks), dim3(256), lds_resident, (hipStream_t)stream, g);
+    return det6d_check_launch("det6d_mlp_rows");
+  }
   // narrow stacks (every layer at most two column tiles, single chain, many rows): 64-row tiles
   int max_tiles = 0;
   for (int c = 0, o = 0; c < nchains; o += nlayers[c], ++c)
