@@ -1,5 +1,7 @@
 # round 5: the round-4 build (git archive of the round-4 commit, built in scratch_r04/) on the long measurement span, beside
 # this round's build: what the round-4 headline was worth without the span bias, and what this round gained
+# scratch_r04/ is not tracked; recreate it HERE (not on the GPU box, which has no .git) before the gpurun call:
+#   mkdir scratch_r04 && git archive 258dc59 | tar -x -C scratch_r04 && (cd scratch_r04 && python -m de6d_amd._build)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=24
 out=$GRAFT_REPO_ROOT/gpurun_out/r05_t25; mkdir -p $out
 summ() { grep '^{' $out/b_$1.log | python3 -c "
