@@ -55,7 +55,23 @@ static inline bool det6d_env_set(const char *name) { return det6d_switch_set(nam
 #define D6_DBG_IS(v) (dbg == (v))
 // DET6D_DBG_POISON_LDS=<pattern>: fill the LDS of every CU before a sampler kernel (fps_seq.hip; tests only)
 void det6d_dbg_poison_lds_hook(hipStream_t stream);
+// DET6D_GEMM_PRIO=1 (experiments build): every wave of the GEMM family raises its issue priority (s_setprio 3) — does the matrix
+// stream lose issue slots to the vector instructions of the kernels beside it?  (scripts/r05/gpu_t34.sh)
+#define D6_GEMM_PRIO_DECL __device__ int d6_gemm_prio_flag = 0;
+#define D6_GEMM_PRIO_APPLY() do { if (d6_gemm_prio_flag) __builtin_amdgcn_s_setprio(3); } while (0)
+#define D6_GEMM_PRIO_HOST()                                                                                  \
+  do {                                                                                                       \
+    static bool d6_p_ = false;                                                                               \
+    if (!d6_p_) {                                                                                            \
+      d6_p_ = true;                                                                                          \
+      const int d6_v_ = det6d_env_int("DET6D_GEMM_PRIO", 0);                                                 \
+      if (d6_v_) (void)hipMemcpyToSymbol(HIP_SYMBOL(d6_gemm_prio_flag), &d6_v_, sizeof(int));                \
+    }                                                                                                        \
+  } while (0)
 #else
+#define D6_GEMM_PRIO_DECL
+#define D6_GEMM_PRIO_APPLY() do {} while (0)
+#define D6_GEMM_PRIO_HOST() do {} while (0)
 static inline int det6d_env_int(const char *, int dflt) { return dflt; }
 static inline bool det6d_env_set(const char *) { return false; }
 #define D6_DBG_IS(v) false

@@ -22,6 +22,8 @@
 
 namespace {
 
+D6_GEMM_PRIO_DECL
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
@@ -41,6 +43,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // the matrix pipe (scripts/hiptests/mfma_valu_overlap.hip), and the predicated form had ~56 of them per slab.
 template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBUF = 1, int FASTLVL = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void linear_kernel(const det6d_linear_args g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr bool FAST = FASTLVL >= 2;      // predicate-free buffer_load main loop
   constexpr bool FAST_EPI = FASTLVL >= 1;  // predicate-free buffer_store epilogue on interior tiles (32-bit offsets)
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
 }  // namespace
 
 DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
+  D6_GEMM_PRIO_HOST();
   if (!a || a->rows < 0 || a->k <= 0 || a->ncols <= 0 || !a->a || !a->w || !a->y) return DET6D_EINVAL;
   if ((a->lda & 3) || (a->ldw & 3) || ((uintptr_t)a->a & 15) || ((uintptr_t)a->w & 15)) return DET6D_EINVAL;
   if (a->k > a->lda || a->ncols > a->ldw) return DET6D_EINVAL;

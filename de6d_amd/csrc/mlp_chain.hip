@@ -22,6 +22,8 @@
 
 namespace {
 
+D6_GEMM_PRIO_DECL
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kChainWaves = 4;
@@ -108,6 +110,7 @@ __device__ __forceinline__ float relu1(float v) { return v > 0.f ? v : 0.f; }
 __host__ __device__ __forceinline__ int chain_col(int j, int k1) { return j + 3 < k1 ? j + 3 : j + 3 - k1; }
 
 __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const ChainArgs g) {
+  D6_GEMM_PRIO_APPLY();
   __shared__ float W1[kMaxK1 * kMaxC];
   __shared__ float W2[kMaxC * kMaxC];
   __shared__ float W3[kMaxC * kMaxC3];
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void mlp_chain_kernel(const Chain
 // Every output is still ONE ascending-k fma chain: bit-identical to det6d_linear x 3.
 template <int C1, int C2, int C3, int NS, bool COMPACT = false>
 __global__ __launch_bounds__(256) void mlp_chain_reg_kernel(const ChainArgs g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr int S1 = 2;            // k1 = 4: [dx, dy, dz, f]
   constexpr int S2 = C1 / 2, S3 = C2 / 2, NT3 = C3 / 32;
   const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
@@ -520,6 +524,7 @@ __device__ __forceinline__ void mfma_steps_lds(const float *__restrict__ w, cons
 // Per tile ~250 vector-ALU ops (ReLU, swaps, pooling) against 17-23 k cycles of matrix work.
 template <int C2, int NS, bool COMPACT = false>
 __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(const ChainArgs g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr int K1 = 68, C1 = 64, C3 = 128;
   constexpr int S1 = K1 / 2, S2 = C1 / 2, S3 = C2 / 2;
   constexpr int T1 = C1 / 32, T2 = C2 / 32, T3 = C3 / 32;
@@ -749,6 +754,7 @@ DET6D_API int det6d_mlp_chain3(int rows, int n, int m, int ns, const float *a, i
                                const float *s1, int c1, const float *w2, int ldw2, const float *s2, int c2,
                                const float *w3, int ldw3, const float *s3, int c3, float *y, int ldy, int col0,
                                det6d_stream_t stream) {
+  D6_GEMM_PRIO_HOST();
   if (rows < 0 || n <= 0 || m <= 0 || (ns != 16 && ns != 32) || !a || !idx || !ctr || !cnt || !w1 || !w2 || !w3 ||
       !s1 || !s2 || !s3 || !y)
     return DET6D_EINVAL;
@@ -813,6 +819,7 @@ DET6D_API int det6d_mlp_chain3_compact(int capacity, const int *hdr, const int *
                                        int lda, const float *ctr, int ldctr, const float *w1, int ldw1, const float *s1,
                                        int c1, const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3,
                                        const float *s3, int c3, float *y, int ldy, int col0, det6d_stream_t stream) {
+  D6_GEMM_PRIO_HOST();
   if (capacity <= 0 || (capacity & 127) || !hdr || !crow_p || !crow_c || !a || !ctr || ldctr < 3 || !w1 || !w2 || !w3 || !s1 ||
       !s2 || !s3 || !y)
     return DET6D_EINVAL;

@@ -23,6 +23,8 @@
 
 namespace {
 
+D6_GEMM_PRIO_DECL
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
@@ -400,6 +402,7 @@ __device__ __forceinline__ void group_pool_store(const GroupArgs &g, const int t
 
 template <int C1, int C2, int C3, bool COMPACT, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && C3 <= 256) ? 3 : 1) void mlp_group_kernel(const GroupArgs g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
   constexpr int TN2 = C2 / (32 * NW), TN3 = C3 / (32 * NW);     // accumulator tiles per wave: a wave owns 1 / NW of every layer's columns
   static_assert(TN2 >= 1 && TN3 >= 1, "every wave needs at least one 32-column tile per layer");
@@ -551,6 +554,7 @@ __device__ __forceinline__ void stream_layer(const float *__restrict__ X, const 
 
 template <int C1, int C2, int C3, bool COMPACT>
 __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArgs g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr int CH = 128;                          // second-layer columns per chunk = third-layer k per chunk
   constexpr int NCH = C2 / CH;
   constexpr int LD1 = C1 + 1, LDY = CH + 1;
@@ -691,6 +695,7 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
                                int c3, const float *pts, int ldpts, const float *ctr, int ldctr, const int *idx, int n, int m,
                                int ns, const int *cnt, const int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
                                int col0, det6d_stream_t stream) {
+  D6_GEMM_PRIO_HOST();
   if (rows < 0 || (rows & 31) || !p || !w1 || !w2 || !w3 || !s1 || !s2 || !s3 || !pts || !ctr || !y) return DET6D_EINVAL;
   if (!group_widths_ok(c1, c2, c3)) return DET6D_EINVAL;
   if ((ldp & 3) || (pcol0 & 3) || (ldw1 & 3) || ldp < pcol0 + c1 || ldw1 < c1 || ldw2 < c2 || ldw3 < c3 || ldpts < 3 || ldctr < 3)

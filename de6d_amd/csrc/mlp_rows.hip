@@ -11,6 +11,8 @@
 
 namespace {
 
+D6_GEMM_PRIO_DECL
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4r __attribute__((ext_vector_type(4)));
 
@@ -31,6 +33,7 @@ struct RowsArgs {
 // and a layer of one keeps two, instead of two and one.
 template <bool CHUNKED, int RB>
 __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
+  D6_GEMM_PRIO_APPLY();
   static_assert(!(CHUNKED && RB != 1), "the K-chunked first layer keeps one accumulator per wave");
   constexpr int TR = 32 * RB;                     // rows per tile
   extern __shared__ float lds[];
@@ -230,6 +233,7 @@ __device__ __forceinline__ f32x16 rows_item(const float *xa, const float (&b)[NB
 
 template <int K0, int K1, int K2>
 __global__ __launch_bounds__(256) void mlp_rows_resident_kernel(const RowsArgs g) {
+  D6_GEMM_PRIO_APPLY();
   constexpr int TR = 64, LDA = K0 + 1, LDB = K1 + 1, NV = K0 / 16;    // NV float4 per thread and input row (4 threads per row)
   static_assert(K0 % 32 == 0 && K1 % 32 == 0 && K2 % 32 == 0 && K2 <= K1 && K1 <= 64 && K2 <= K0, "SA1-shaped stacks only");
   extern __shared__ float lds[];
@@ -383,6 +387,7 @@ DET6D_API int det6d_mlp_rows_supported(int nchains, const int *nlayers, const de
 
 DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int nchains, const int *nlayers,
                              const det6d_rows_layer *layers, det6d_stream_t stream) {
+  D6_GEMM_PRIO_HOST();
   if (rows < 0 || !x || ldx <= 0 || xcol0 < 0) return DET6D_EINVAL;
   RowsArgs g;
   if (rows_plan(nchains, nlayers, layers, g) != DET6D_OK) return DET6D_EINVAL;
