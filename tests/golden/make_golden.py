@@ -23,6 +23,8 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    numba.cuda launch of rotate_iou_gpu_eval replaced by a loop over the reference's own
                    devRotateIoUEval device function)
   extension_api.json  names + positional arities of the reference's two pybind modules (parsed from its *_api.cpp and headers)
+  det6d_full.npz, det6d_full_sloped.npz, det6d_full_3class.npz   the same whole-model golden at the FULL widths of
+                   BASELINE configs[1] (two scenes), [2] and [3] (gen_model_full, gen_model_full_other)
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -297,7 +299,7 @@ FULL_CASES = (  # name, scene generator, scene seed, tilt
 )
 
 
-def gen_model_full():
+def gen_model_full(cfg_rel='kitti_models/det6d_car.yaml', out_name='det6d_full.npz', cases=None, weight_seed=31):
     """det6d_car.yaml (the benchmarked widths: K up to 1536, twelve stacked layers between the input and the boxes) through
     the REFERENCE's own Python model (pointnet2_backbone.py:199-263, point_head_box6d_vote.py:794-903,
     detector3d_template.py:178-284; torch-CPU Conv/BN/ReLU), one 16384-point scene per case, the oracle's ops behind the
@@ -313,9 +315,9 @@ def gen_model_full():
     assert ref_models.__file__.startswith(REF)
     from tests import util as tutil
     from de6d_amd.runtime import load_config, build_model
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "de6d_amd/cfgs/kitti_models/det6d_car.yaml")))
-    weight_seed = 31
-    ours = build_model(load_config('kitti_models/det6d_car.yaml'), seed=weight_seed)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "de6d_amd/cfgs", cfg_rel)))
+    cases = FULL_CASES if cases is None else cases
+    ours = build_model(load_config(cfg_rel), seed=weight_seed)
     sd = ours.state_dict()
 
     class DS(object):
@@ -326,12 +328,12 @@ def gen_model_full():
         point_cloud_range = np.array(cfg['DATA_CONFIG']['POINT_CLOUD_RANGE'], np.float32)
         depth_downsample_factor = None
 
-    ref = ref_models.build_network(EasyDict(cfg['MODEL']), num_class=1, dataset=DS())
+    ref = ref_models.build_network(EasyDict(cfg['MODEL']), num_class=len(cfg['CLASS_NAMES']), dataset=DS())
     assert list(ref.state_dict().keys()) == list(sd.keys())
     ref.load_state_dict(sd)
     ref.eval()
-    out = dict(weight_seed=np.int64(weight_seed), n=np.int64(16384), cases=np.array([c[0] for c in FULL_CASES]))
-    for name, gen, seed, tilt in FULL_CASES:
+    out = dict(weight_seed=np.int64(weight_seed), n=np.int64(16384), cases=np.array([c[0] for c in cases]), cfg=np.array(cfg_rel))
+    for name, gen, seed, tilt in cases:
         b, n = 1, 16384
         batch = getattr(tutil, gen)(seed, b, n, tilt=tilt)
         pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
@@ -355,9 +357,17 @@ def gen_model_full():
         out[name + '_pred_boxes'] = p['pred_boxes'].numpy()
         out[name + '_pred_scores'] = p['pred_scores'].numpy()
         out[name + '_pred_labels'] = p['pred_labels'].numpy()
-        print("det6d_full %s: %d detections" % (name, len(p['pred_scores'])))
-    np.savez_compressed(os.path.join(HERE, "det6d_full.npz"), **out)
-    print("det6d_full.npz", os.path.getsize(os.path.join(HERE, "det6d_full.npz")), "bytes")
+        print("%s %s: %d detections, labels %s" % (out_name, name, len(p['pred_scores']), np.unique(p['pred_labels'].numpy())))
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+    print(out_name, os.path.getsize(os.path.join(HERE, out_name)), "bytes")
+
+
+def gen_model_full_other():
+    """the same pin for the other two model configurations of BASELINE.json at their full widths: configs[2] SlopedKITTI Car
+    (ground-aware pitch branch of the box coder and the head, on a tilted ray-cast scene) and configs[3] KITTI 3-class (three
+    class logits per candidate, per-class anchors) — det6d_full_sloped.npz / det6d_full_3class.npz"""
+    gen_model_full('slopedkitti_models/det6d_car.yaml', 'det6d_full_sloped.npz', (('beam', 'beam_batch', 4300, True),), weight_seed=37)
+    gen_model_full('kitti_models/det6d_3class.yaml', 'det6d_full_3class.npz', (('beam', 'beam_batch', 4400, False),), weight_seed=41)
 
 
 # ----------------------------------------------------------------------------- feature propagation, boxes_iou3d_gpu
@@ -732,6 +742,7 @@ if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
     gens = dict(nms=gen_nms, box_coder=gen_box_coder, model=gen_model, producer=gen_producer, annos=gen_annos,
-                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, fp=gen_fp, extension_api=gen_extension_api)
+                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, model_full_other=gen_model_full_other, fp=gen_fp,
+                extension_api=gen_extension_api)
     for name in (sys.argv[1:] or list(gens)):      # `python make_golden.py model_full` regenerates one fixture
         gens[name]()

@@ -79,16 +79,17 @@ def test_whole_model_against_reference_python_golden():
         assert (d.min(axis=1) < 1e-4).all() and (d.min(axis=0) < 1e-4).all()
 
 
-@pytest.mark.parametrize("name", ["uniform", "beam"])
-def test_full_width_model_against_reference_python_golden(name):
+@pytest.mark.parametrize("fixture,name", [("det6d_full.npz", "uniform"), ("det6d_full.npz", "beam"),
+                                          ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam")])
+def test_full_width_model_against_reference_python_golden(fixture, name):
     """kitti_models/det6d_car.yaml — the benchmarked widths (K up to 1536) — one 16384-point scene per case, HIP path vs the
     reference's own Python model (tests/golden/det6d_full.npz, make_golden.py: gen_model_full): sampled point sets of all
     three levels identical (D-FPS and S-FPS picks), confidence scores, vote points, box codes, decoded boxes and class
     logits within 1e-4 abs, kept detections the same set."""
     from de6d_amd.runtime import load_config, build_model
     from tests.test_oracle_golden import full_case_inputs
-    z = np.load(os.path.join(G, 'det6d_full.npz'))
-    cfg = load_config('kitti_models/det6d_car.yaml')
+    z = np.load(os.path.join(G, fixture))
+    cfg = load_config(str(z['cfg']) if 'cfg' in z.files else 'kitti_models/det6d_car.yaml')   # (sloped Car and 3-class: round 5)
     model = build_model(cfg, seed=int(z['weight_seed']), device='cuda')
     bd = {'batch_size': 1, 'points': torch.from_numpy(full_case_inputs(z, name)).cuda()}
     with torch.no_grad():

@@ -145,15 +145,20 @@ def compare_full_case(z, name, got, tol=1e-4):
     return 0
 
 
-@pytest.mark.parametrize("name", ["uniform", "beam"])
-def test_full_width_model_against_reference_python(oracle_ops, name):
-    """kitti_models/det6d_car.yaml (K up to 1536, the benchmarked widths), one 16384-point scene: oracle/model.py vs the
-    reference's own Python model.  North star: identical sampled point sets at all three levels (the S-FPS picks depend on
+FULL_GOLDEN = [("det6d_full.npz", "uniform"), ("det6d_full.npz", "beam"),
+               ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam")]
+
+
+@pytest.mark.parametrize("fixture,name", FULL_GOLDEN)
+def test_full_width_model_against_reference_python(oracle_ops, fixture, name):
+    """kitti_models/det6d_car.yaml (K up to 1536, the benchmarked widths; BASELINE configs[1]) and, from round 5 on, the
+    SlopedKITTI Car (configs[2]: ground-aware pitch branch, tilted ray-cast scene) and KITTI 3-class (configs[3]) models at
+    their full widths, one 16384-point scene each: oracle/model.py vs the reference's own Python model.  North star: identical sampled point sets at all three levels (the S-FPS picks depend on
     confidence scores that went through up to nine stacked layers), boxes / poses within 1e-4 abs."""
     from de6d_amd.runtime import load_config, build_model
     from oracle import model as omodel
-    z = np.load(os.path.join(G, 'det6d_full.npz'))
-    cfg = load_config('kitti_models/det6d_car.yaml')
+    z = np.load(os.path.join(G, fixture))
+    cfg = load_config(str(z['cfg']) if 'cfg' in z.files else 'kitti_models/det6d_car.yaml')
     model = build_model(cfg, seed=int(z['weight_seed']))
     sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
     got = omodel.forward(cfg.MODEL, sd, full_case_inputs(z, name), 1)
