@@ -23,8 +23,9 @@ writes are data (inputs + expected outputs) and are what travels to the GPU box.
                    numba.cuda launch of rotate_iou_gpu_eval replaced by a loop over the reference's own
                    devRotateIoUEval device function)
   extension_api.json  names + positional arities of the reference's two pybind modules (parsed from its *_api.cpp and headers)
-  det6d_full.npz, det6d_full_sloped.npz, det6d_full_3class.npz   the same whole-model golden at the FULL widths of
-                   BASELINE configs[1] (two scenes), [2] and [3] (gen_model_full, gen_model_full_other)
+  det6d_full.npz, det6d_full_sloped.npz, det6d_full_3class.npz, det6d_full_65536.npz   the same whole-model golden at the
+                   FULL widths of BASELINE configs[1] (two scenes), [2], [3] and [4] (one 65536-point scene)
+                   (gen_model_full, gen_model_full_other, gen_model_full_65536)
   det6d_tiny.npz   whole-model golden: the reference's Python model code (PointNet2FSMSG,
                    PointHeadBox6DVote, Detector3DTemplate.post_processing; torch-CPU Conv/BN/ReLU)
                    built from tests' tiny config with seeded weights, run on seeded scenes.  Its
@@ -299,7 +300,7 @@ FULL_CASES = (  # name, scene generator, scene seed, tilt
 )
 
 
-def gen_model_full(cfg_rel='kitti_models/det6d_car.yaml', out_name='det6d_full.npz', cases=None, weight_seed=31):
+def gen_model_full(cfg_rel='kitti_models/det6d_car.yaml', out_name='det6d_full.npz', cases=None, weight_seed=31, n_points=16384):
     """det6d_car.yaml (the benchmarked widths: K up to 1536, twelve stacked layers between the input and the boxes) through
     the REFERENCE's own Python model (pointnet2_backbone.py:199-263, point_head_box6d_vote.py:794-903,
     detector3d_template.py:178-284; torch-CPU Conv/BN/ReLU), one 16384-point scene per case, the oracle's ops behind the
@@ -332,9 +333,9 @@ def gen_model_full(cfg_rel='kitti_models/det6d_car.yaml', out_name='det6d_full.n
     assert list(ref.state_dict().keys()) == list(sd.keys())
     ref.load_state_dict(sd)
     ref.eval()
-    out = dict(weight_seed=np.int64(weight_seed), n=np.int64(16384), cases=np.array([c[0] for c in cases]), cfg=np.array(cfg_rel))
+    out = dict(weight_seed=np.int64(weight_seed), n=np.int64(n_points), cases=np.array([c[0] for c in cases]), cfg=np.array(cfg_rel))
     for name, gen, seed, tilt in cases:
-        b, n = 1, 16384
+        b, n = 1, n_points
         batch = getattr(tutil, gen)(seed, b, n, tilt=tilt)
         pts = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n)[:, None], batch.reshape(b * n, 4)], 1).astype(np.float32)
         bd = {'batch_size': b, 'points': torch.from_numpy(pts)}
@@ -352,7 +353,9 @@ def gen_model_full(cfg_rel='kitti_models/det6d_car.yaml', out_name='det6d_full.n
                     'vote_offsets'):
             out[name + '_' + key] = bd[key].numpy()
         # 512-wide features: keep a strided sample (the whole tensor is 0.5 MB per case)
-        out[name + '_point_features_s8'] = bd['point_features'].numpy()[:, ::8]
+        fstride = 8 if n_points <= 16384 else 32          # (key name kept from the first fixture; the stride travels beside it)
+        out['features_stride'] = np.int64(fstride)
+        out[name + '_point_features_s8'] = bd['point_features'].numpy()[:, ::fstride]
         p = pred[0]
         out[name + '_pred_boxes'] = p['pred_boxes'].numpy()
         out[name + '_pred_scores'] = p['pred_scores'].numpy()
@@ -368,6 +371,13 @@ def gen_model_full_other():
     class logits per candidate, per-class anchors) — det6d_full_sloped.npz / det6d_full_3class.npz"""
     gen_model_full('slopedkitti_models/det6d_car.yaml', 'det6d_full_sloped.npz', (('beam', 'beam_batch', 4300, True),), weight_seed=37)
     gen_model_full('kitti_models/det6d_3class.yaml', 'det6d_full_3class.npz', (('beam', 'beam_batch', 4400, False),), weight_seed=41)
+
+
+def gen_model_full_65536():
+    """BASELINE configs[4]: one 65536-point scene through the reference's Python model (16384 / 2048+2048 / 1024+1024 sampled
+    points: the sizes the cooperative sampler and the large-cloud ball query serve) — det6d_full_65536.npz"""
+    gen_model_full('synthetic_models/det6d_65536.yaml', 'det6d_full_65536.npz', (('uniform', 'make_batch', 4500, False),), weight_seed=43,
+                   n_points=65536)
 
 
 # ----------------------------------------------------------------------------- feature propagation, boxes_iou3d_gpu
@@ -742,7 +752,7 @@ if __name__ == "__main__":
     oops.build()
     assert oref.available(), "build oracle/_ref first: make -C oracle _ref"
     gens = dict(nms=gen_nms, box_coder=gen_box_coder, model=gen_model, producer=gen_producer, annos=gen_annos,
-                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, model_full_other=gen_model_full_other, fp=gen_fp,
+                slope=gen_slope, eval=gen_eval, model_full=gen_model_full, model_full_other=gen_model_full_other, model_full_65536=gen_model_full_65536, fp=gen_fp,
                 extension_api=gen_extension_api)
     for name in (sys.argv[1:] or list(gens)):      # `python make_golden.py model_full` regenerates one fixture
         gens[name]()

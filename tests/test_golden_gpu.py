@@ -80,7 +80,8 @@ def test_whole_model_against_reference_python_golden():
 
 
 @pytest.mark.parametrize("fixture,name", [("det6d_full.npz", "uniform"), ("det6d_full.npz", "beam"),
-                                          ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam")])
+                                          ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam"),
+                                          ("det6d_full_65536.npz", "uniform")])
 def test_full_width_model_against_reference_python_golden(fixture, name):
     """kitti_models/det6d_car.yaml — the benchmarked widths (K up to 1536) — one 16384-point scene per case, HIP path vs the
     reference's own Python model (tests/golden/det6d_full.npz, make_golden.py: gen_model_full): sampled point sets of all
@@ -99,7 +100,8 @@ def test_full_width_model_against_reference_python_golden(fixture, name):
     for lvl in (0, 1):
         np.testing.assert_allclose(bd['point_scores_list'][lvl].cpu().numpy().reshape(-1),
                                    z['%s_point_scores_list_%d' % (name, lvl)].reshape(-1), atol=1e-4)
-    np.testing.assert_allclose(bd['point_features'].cpu().numpy()[:, ::8], z[name + '_point_features_s8'], atol=1e-4)
+    fstride = int(z['features_stride']) if 'features_stride' in z.files else 8
+    np.testing.assert_allclose(bd['point_features'].cpu().numpy()[:, ::fstride], z[name + '_point_features_s8'], atol=1e-4)
     for key in ('point_candidate_coords', 'point_vote_coords', 'batch_cls_preds', 'batch_box_preds', 'point_reg_preds',
                 'vote_offsets'):
         np.testing.assert_allclose(bd[key].cpu().numpy(), z[name + '_' + key], atol=1e-4, err_msg=key)

@@ -128,7 +128,8 @@ def compare_full_case(z, name, got, tol=1e-4):
     for lvl in (0, 1):
         np.testing.assert_allclose(got['l_scores'][lvl].reshape(-1), z['%s_point_scores_list_%d' % (name, lvl)].reshape(-1),
                                    atol=tol, err_msg='confidence scores of level %d' % lvl)
-    np.testing.assert_allclose(got['point_features'][:, ::8], z[name + '_point_features_s8'], atol=tol)
+    fstride = int(z['features_stride']) if 'features_stride' in z.files else 8
+    np.testing.assert_allclose(got['point_features'][:, ::fstride], z[name + '_point_features_s8'], atol=tol)
     np.testing.assert_array_equal(got['point_candidate_coords'], z[name + '_point_candidate_coords'][:, 1:])
     np.testing.assert_allclose(got['point_vote_coords'], z[name + '_point_vote_coords'][:, 1:], atol=tol)
     np.testing.assert_allclose(got['vote_offsets'], z[name + '_vote_offsets'].transpose(0, 2, 1).reshape(-1, 3), atol=tol)   # reference layout (B, 3, P)
@@ -146,14 +147,15 @@ def compare_full_case(z, name, got, tol=1e-4):
 
 
 FULL_GOLDEN = [("det6d_full.npz", "uniform"), ("det6d_full.npz", "beam"),
-               ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam")]
+               ("det6d_full_sloped.npz", "beam"), ("det6d_full_3class.npz", "beam"), ("det6d_full_65536.npz", "uniform")]
 
 
 @pytest.mark.parametrize("fixture,name", FULL_GOLDEN)
 def test_full_width_model_against_reference_python(oracle_ops, fixture, name):
     """kitti_models/det6d_car.yaml (K up to 1536, the benchmarked widths; BASELINE configs[1]) and, from round 5 on, the
     SlopedKITTI Car (configs[2]: ground-aware pitch branch, tilted ray-cast scene) and KITTI 3-class (configs[3]) models at
-    their full widths, one 16384-point scene each: oracle/model.py vs the reference's own Python model.  North star: identical sampled point sets at all three levels (the S-FPS picks depend on
+    their full widths, one 16384-point scene each, and one 65536-point scene through configs[4]'s model: oracle/model.py vs the
+    reference's own Python model.  North star: identical sampled point sets at all three levels (the S-FPS picks depend on
     confidence scores that went through up to nine stacked layers), boxes / poses within 1e-4 abs."""
     from de6d_amd.runtime import load_config, build_model
     from oracle import model as omodel
