@@ -74,7 +74,8 @@ sys.path.insert(0, ROOT)
 from de6d_amd.runtime import ScenePipeline, load_config, build_model, mlp_flops_per_scene, GraphedDet6D  # noqa: E402
 from de6d_amd import synthetic  # noqa: E402
 from bench_legs import (span_windows, window_times, delivery_fit, MAIN_STREAMS, SAMPLER_STREAMS, coalesce_factor, compact_fill, index_kernel_rates,  # noqa: E402
-                        input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, scenes_per_pass_target, selfcheck)
+                        input_producer_rate, linear_roofline, measured_traffic, pipeline_rate, scenes_per_pass_target, selfcheck,
+                        ClockPowerSampler, whole_path_scalars)
 
 
 def synth_points(seed0, b, n, tilt=False, scene='uniform'):
@@ -175,7 +176,20 @@ def orchestrate(args):
             if isinstance(line.get("roofline"), dict) and ray.get("roofline"):
                 line["roofline"]["raycast"] = {"scenes_per_s": ray["scenes_per_s"], "frac": ray["roofline"]["frac"],
                                                "achieved": ray["roofline"]["achieved"],
+                                               "family_frac_idle": ray["roofline"].get("family_frac_idle"),
+                                               "family_frac_saturated": ray["roofline"].get("family_frac_saturated"),
+                                               "sclk_mhz": ray["roofline"].get("sclk_mhz"), "power_w": ray["roofline"].get("power_w"),
                                                "algorithmic_gflop_per_pass": ray["roofline"]["algorithmic_gflop_per_pass"]}
+                line["roofline"]["raycast_whole_path_frac"] = ray["roofline"].get("whole_path_frac")
+                line["roofline"]["raycast_scenes_per_s"] = ray["scenes_per_s"]
+        big = line["other_configs"].get(legs[2][0], {})
+        if isinstance(line.get("roofline"), dict) and big.get("roofline"):
+            line["roofline"]["cfg5_whole_path_frac"] = big["roofline"].get("whole_path_frac")
+            line["roofline"]["cfg5_scenes_per_s"] = big.get("scenes_per_s")
+            line["roofline"]["cfg5_sclk_mhz"] = big["roofline"].get("sclk_mhz")
+        dense = line.get("dense_rows") or {}
+        if isinstance(line.get("roofline"), dict) and dense.get("roofline"):
+            line["roofline"]["dense_rows_whole_path_frac"] = dense["roofline"].get("whole_path_frac")
         # Operating points (round-4 review item 7): the same engine at other points of its throughput / latency curve.
         # `value` is the CLOSED loop (a new pass the moment a slot frees: every queue full, latency = queueing).  The PACED legs
         # are an OPEN loop, the shape of a sensor: passes are issued on a fixed cadence (ScenePipeline.run headway) chosen as a
@@ -206,6 +220,7 @@ def orchestrate(args):
                                   scenes_per_pass=args.batch * args.merge)
             if tr is not None:
                 line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_bytes_per_scene"] = round(tr["hbm_bytes_per_launch"] * tr["launches_per_pass"] / tr["scenes_per_pass"])
                 line["roofline"]["traffic_source"] = "measured in this run"
                 line["roofline"]["traffic_detail"] = tr
             elif line["roofline"].get("traffic_source"):
@@ -431,6 +446,7 @@ def main():
         if first < step <= first + args.steps:
             dets[0] += sum(len(p['pred_scores']) for p in preds)
 
+    sampler = ClockPowerSampler() if (rank == 0 and world == 1) else None     # shader clock + socket power over the stream
     bracket()
     GraphedDet6D.host_wait_s = 0.0
     GraphedDet6D.stamp_launches = device_clock
@@ -438,9 +454,12 @@ def main():
     origin.record()
     origin.synchronize()                   # the device is idle here: the event's device time == this host time (to ~10 us)
     t_origin = t_stream = time.perf_counter()
+    t_wall0 = time.time()
     run(last + 1 + tail, on_done)
     bracket()
     t_stream = time.perf_counter() - t_stream
+    # (the pipeline's fill and the pre-roll are left out: the first quarter of the stream)
+    clocks = sampler.stop(t_wall0 + 0.25 * t_stream, t_wall0 + t_stream) if sampler is not None else None
     GraphedDet6D.stamp_launches = False
     host_wait = GraphedDet6D.host_wait_s
     if device_clock:
@@ -583,6 +602,7 @@ def main():
             line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS)
             line["roofline"]["scenes_per_pass"] = b * merge
             line["roofline"]["steps_per_pass"] = merge
+            whole_path_scalars(line["roofline"], b * merge, line["value"], clocks)
             line["compact_fill"] = compact_fill(model, points, b)
             line["index_kernels"] = index_kernel_rates(model, points, b, n)
             line["input_producer"] = input_producer_rate(cfg, b)
@@ -593,11 +613,14 @@ def main():
             line["roofline"] = linear_roofline(model, pass_inputs[0], b * merge, flops, streams=MAIN_STREAMS,
                                                pmc_tag='65536' if n == 65536 else args.scene)
             line["roofline"]["scenes_per_pass"] = b * merge
+            whole_path_scalars(line["roofline"], b * merge, line["value"], clocks)
             line["compact_fill"] = compact_fill(model, points, b)
             if n != 16384:               # the samplers / queries of this leg's shapes (the 65536-point cooperative sampler)
                 line["index_kernels"] = index_kernel_rates(model, points, b, n)
         elif world == 1:
             line["compact_fill"] = compact_fill(model, points, b)
+        if clocks:
+            line["clocks"] = {"sclk_mhz": clocks["sclk_mhz"], "power_w": clocks["power_w"]}
         if world == 1 and args.cpu_scenes > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, model, pts_np, args.cpu_scenes)
         print(json.dumps(line), flush=True)

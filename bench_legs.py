@@ -20,6 +20,111 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 HBM_PEAK_GBS = 8000.0
 
 
+_SAMPLER_CODE = r"""
+import glob, sys, time
+out = open(sys.argv[1], 'w')
+period = float(sys.argv[2])
+smi = h = None
+try:                                   # amdsmi: gfx clock of every XCD + socket power (no HIP context is created)
+    import amdsmi as smi
+    smi.amdsmi_init()
+    h = smi.amdsmi_get_processor_handles()[0]
+    smi.amdsmi_get_gpu_metrics_info(h)['current_gfxclks']
+except Exception:
+    smi = None
+hw = [d for d in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*') if glob.glob(d + '/freq1_input')]
+while True:
+    t = time.time()
+    clk = pw = None
+    try:
+        if smi is not None:
+            m = smi.amdsmi_get_gpu_metrics_info(h)
+            c = [float(x) for x in m['current_gfxclks'] if isinstance(x, (int, float)) and 0 < x < 10000]
+            clk = sum(c) / len(c) if c else None
+            p = m.get('current_socket_power')
+            pw = float(p) if isinstance(p, (int, float)) else None
+        elif hw:
+            clk = float(open(hw[0] + '/freq1_input').read()) / 1e6
+            pw = float(open(hw[0] + '/power1_input').read()) / 1e6
+    except Exception:
+        pass
+    out.write('%.4f %s %s\n' % (t, 'nan' if clk is None else '%.1f' % clk, 'nan' if pw is None else '%.1f' % pw))
+    out.flush()
+    time.sleep(period)
+"""
+
+
+class ClockPowerSampler(object):
+    """round-5 review item 2: average shader clock and socket power OVER THE TIMED STREAM.  A child process that never
+    touches HIP polls amdsmi's gpu_metrics (current_gfxclks of the 8 XCDs, current_socket_power; sysfs hwmon freq1_input /
+    power1_input as the fall-back) every `period` s and stamps the samples with the host clock; the worker keeps the samples
+    between the two barriers of the stream.  The firmware refreshes gpu_metrics about once a millisecond; the values are
+    instantaneous, so the mean over a >= 2 s stream is what is reported."""
+
+    def __init__(self, period=0.02):
+        import subprocess
+        import sys
+        import tempfile
+        self.path = tempfile.mktemp(prefix='det6d_clk_')
+        try:
+            self.proc = subprocess.Popen([sys.executable, '-c', _SAMPLER_CODE, self.path, str(period)],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def stop(self, t0, t1):
+        """samples with t0 <= t <= t1 (time.time()) -> {'sclk_mhz', 'power_w', ...} or None"""
+        if self.proc is None:
+            return None
+        self.proc.terminate()
+        try:
+            self.proc.wait(timeout=5)
+        except Exception:
+            self.proc.kill()
+        try:
+            rows = [l.split() for l in open(self.path) if len(l.split()) == 3]
+            os.remove(self.path)
+        except Exception:
+            return None
+        rows = [(float(a), float(b_), float(c)) for a, b_, c in rows if t0 <= float(a) <= t1]
+        clk = sorted(c for _, c, _ in rows if c == c)
+        pw = sorted(p for _, _, p in rows if p == p)
+        if not clk:
+            return None
+        return {"sclk_mhz": round(sum(clk) / len(clk), 1), "sclk_mhz_p10_p50_p90": [clk[len(clk) // 10], clk[len(clk) // 2], clk[(9 * len(clk)) // 10]],
+                "power_w": round(sum(pw) / len(pw), 1) if pw else None,
+                "power_w_p10_p50_p90": [pw[len(pw) // 10], pw[len(pw) // 2], pw[(9 * len(pw)) // 10]] if pw else None,
+                "samples": len(clk), "seconds": round(t1 - t0, 3),
+                "source": "amdsmi gpu_metrics (current_gfxclks mean over XCDs, current_socket_power; sysfs hwmon fall-back), polled by a "
+                          "child process over the timed stream"}
+
+
+def whole_path_scalars(roof, scenes_per_pass, scenes_per_s, clocks=None, nominal_mhz=2400.0):
+    """round-5 review item 6: scalars at the TOP of `roofline` (nested objects do not reach the driver's `parsed`).
+    roofline.frac / achieved become the DRIVER-TIMED whole-path figure: algorithmic GFLOP per scene (rows that carry
+    information, every pointwise layer) x `value` / the fp32 MFMA peak.  The launch-by-launch family figures move to
+    family_frac_idle / family_frac_saturated, the longest launch to dominant_launch_frac."""
+    gf = roof["algorithmic_gflop_per_pass"] / float(scenes_per_pass)
+    roof["family_frac_idle"] = roof["frac"]
+    roof["family_tflops_idle"] = roof["achieved"]
+    roof["family_frac_saturated"] = (roof.get("saturated") or {}).get("frac")
+    roof["dominant_launch_frac"] = (roof.get("dominant_launch") or {}).get("frac")
+    roof["algorithmic_gflop_per_scene"] = round(gf, 4)
+    tf = gf * scenes_per_s / 1e3
+    roof["achieved"] = round(tf, 2)
+    roof["frac"] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
+    roof["whole_path_frac"] = roof["frac"]
+    roof["frac_is"] = ("driver-timed whole path: algorithmic_gflop_per_scene x value / peak (every kernel of the pass inside the "
+                       "time, only the MLP family's flops counted); family_frac_idle = the GEMM family launch by launch with HIP "
+                       "events on an idle chip, family_frac_saturated = the same launches with the chip full of them")
+    if clocks:
+        roof["sclk_mhz"] = clocks["sclk_mhz"]
+        roof["power_w"] = clocks["power_w"]
+        roof["whole_path_frac_at_held_clock"] = round(roof["frac"] * nominal_mhz / clocks["sclk_mhz"], 4)
+        roof["clock_power_detail"] = clocks
+    return roof
+
+
 def index_kernel_rates(model, points, batch, n):
     """pair-evaluations per second of the two search kernels, timed stand-alone with HIP
     events on their launch stream at the workload's SA1 shapes"""

@@ -483,6 +483,9 @@ DET6D_API int64_t det6d_ball_query_grid_workspace_bytes(int b, int n) {
 static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int ns_a, float rin_b, float rout_b, int ns_b,
                              const float *new_xyz, const float *xyz, void *workspace, int *cnt_a, int *idx_a, int *cnt_b,
                              int *idx_b, bool pad, const CompactCountArgs *count, hipStream_t s, const char *what) {
+  // index rows leave as 16-byte stores when nsample is a multiple of 4: the idx buffers must then be 16-byte aligned
+  // (det6d_ops.h says so; checked BEFORE anything is queued)
+  if (((ns_a & 3) == 0 && ((uintptr_t)idx_a & 15)) || ((ns_b & 3) == 0 && ((uintptr_t)idx_b & 15))) return DET6D_EINVAL;
   // workspace layout: headers | cell_start | sorted (x, y, z, index) records
   char *ws = (char *)workspace;
   GridHeader *hdr = (GridHeader *)ws;
@@ -491,6 +494,8 @@ static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int
   off += ((size_t)b * (kGridCells + 1) * 4 + 63) / 64 * 64;
   float4 *sorted_pts = (float4 *)(ws + off);
   const float rmax = rout_a > rout_b ? rout_a : rout_b;
+  // (the build kernel's PACKED 16-bit cell counters hold scenes of <= 32768 points; the query's 16-bit per-lane hit lists
+  // hold point indices < 65536: two different limits, `narrow` below)
   if (n <= 32768) hipLaunchKernelGGL(bq_grid_build_kernel<true>, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start, sorted_pts);
   else hipLaunchKernelGGL(bq_grid_build_kernel<false>, dim3(b), dim3(kBuildThreads), 0, s, n, rmax, xyz, hdr, cell_start, sorted_pts);
   QueryArgs qa;
@@ -504,8 +509,6 @@ static int launch_grid_query(int b, int n, int m, float rin_a, float rout_a, int
   qa.light_cap = light_cap < 0 ? 0 : light_cap;
   static const int fixed_cut = det6d_env_int("DET6D_BQ_CUT", 0);
   qa.fixed_cut = fixed_cut;
-  // index rows leave as 16-byte stores when nsample is a multiple of 4 (idx rows are then 16-byte aligned like their buffers)
-  if (((ns_a & 3) == 0 && ((uintptr_t)idx_a & 15)) || ((ns_b & 3) == 0 && ((uintptr_t)idx_b & 15))) return DET6D_EINVAL;
   const bool narrow = n <= 65536;                  // point indices fit 16 bits: half the LDS per workgroup
   const size_t lds = (size_t)(ns_a + ns_b) * kLaneThreads * (narrow ? 2 : 4);
   const dim3 grid(det6d_divup(m, kLaneThreads), b), block(kLaneThreads);

@@ -461,12 +461,17 @@ int launch_fps(int b, int n, int m, const float *xyz, const float *weights, floa
   do {                                                                                         \
     int lp = 0;                                                                                \
     while ((1 << lp) < ppt) ++lp;                                                              \
-    static const unsigned hog = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W>, 1024);        \
     if (flags) {                                                                               \
-      hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
+      /* the opt-in for the dynamic LDS belongs to the instantiation that is launched; a failed first launch must not be  */ \
+      /* followed by the guarded one (it would read flag words nobody wrote)                                              */ \
+      static const unsigned hogw = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W, W>, 1024);  \
+      hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W, W>), grid, dim3(1 << LT), hogw, stream, n, m, log2s, \
                          lp, xyz, weights, temp, idx, vw, flags);                              \
+      const int rc_first = det6d_check_launch("det6d_fps (fp32 scoring)");                     \
+      if (rc_first != DET6D_OK) return rc_first;                                               \
       hipLaunchKernelGGL((fps_mem_kernel<W>), grid, dim3(S < 64 ? 64 : S), 0, stream, n, m, log2s, xyz, weights, temp, idx, vw, 1); \
     } else {                                                                                   \
+      static const unsigned hog = det6d_sampler_lds_hog(fps_fat_kernel<LT, SL, W>, 1024);      \
       hipLaunchKernelGGL((fps_fat_kernel<LT, SL, W>), grid, dim3(1 << LT), hog, stream, n, m, log2s, \
                          lp, xyz, weights, temp, idx, vw, nullptr);                            \
     }                                                                                          \
@@ -566,6 +571,7 @@ __global__ __launch_bounds__(512) void fps_standin_kernel(int n, int m, int *idx
 // fps_coop.hip: register-resident D-FPS of 32768 / 65536-point scenes by cooperating workgroups
 bool det6d_fps_coop_handles(int n);
 long long det6d_fps_coop_workspace_bytes(int b, int n);
+bool det6d_fps_coop_fits_device(int n);      // fps_coop.hip: the current device holds one cooperative launch (>= 8 x parts CUs)
 int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream);
 
@@ -625,7 +631,7 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   // 32768 / 65536 points: the scene is held in registers by 2 / 4 cooperating workgroups (fps_coop.hip) when the caller
   // supplied the workspace det6d_fps_fused_workspace_bytes asks for; otherwise the memory-resident kernel below, 100x
   // slower, same picks
-  if (temp && x && out && b > 0 && m > 0 && det6d_fps_coop_handles(n)) {
+  if (temp && x && out && b > 0 && m > 0 && det6d_fps_coop_handles(n) && det6d_fps_coop_fits_device(n)) {
     char *ws = reinterpret_cast<char *>(((uintptr_t)temp + 255) & ~(uintptr_t)255);
     const long long avail = temp_bytes - (ws - reinterpret_cast<char *>(temp));
     const long long need = det6d_fps_coop_workspace_bytes(b, n);

@@ -672,6 +672,25 @@ long long det6d_fps_coop_workspace_bytes(int b, int n) {
 int det6d_fps_cell_sort_parts(int subscenes, int parts, int log2s, long long xyz_bstride, const float *xyz, const int *src, int *perm,
                               hipStream_t stream);      // fps_cells.hip
 
+// CU count of the CURRENT device (cached per device: a process may drive several)
+static int coop_device_cus() {
+  static int cus_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus_of[dev] <= 0) {
+    hipDeviceProp_t prop;
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus_of[dev];
+}
+// A sampling launch covers scenes in multiples of 8 (the block -> scene map) with `parts` co-resident 1024-thread workgroups
+// each: a device (or partition) with fewer than 8 x parts CUs cannot hold one such launch — its workgroups would poll partners
+// that are never scheduled until the 2 s time-out — so det6d_fps_fused routes such a device to the memory-resident sampler
+// (same picks) and det6d_fps_coop_launch refuses before anything is queued.
+bool det6d_fps_coop_fits_device(int n) {
+  return det6d_fps_coop_handles(n) && coop_device_cus() >= 8 * (n / kPartPoints);
+}
+
 int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream) {
   if (!det6d_fps_coop_handles(n) || b <= 0 || b > 4096 || !workspace || ((uintptr_t)workspace & 255)) return DET6D_EINVAL;
@@ -682,6 +701,11 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   unsigned long long *exch = (unsigned long long *)(ws + L.exch);
   int *err = (int *)(ws + L.err);
   const int parts = n / kPartPoints;
+  if (!det6d_fps_coop_fits_device(n)) {
+    det6d_set_error("det6d_fps (cooperative): the device has fewer than 8 x parts compute units", hipErrorInvalidConfiguration);
+    return DET6D_EINVAL;
+  }
+  const int cus = coop_device_cus();
   static const int multi = det6d_env_int("DET6D_FPS_COOP_MULTI", 1);      // experiments build: 0 = the one-pick kernel
   const int exch_words = multi ? (int)coop_multi_words(parts, kMultiCands) : 2 * parts * kSlotWords;
   // pre-pass: spatial parts of 16384 points, then the single-workgroup sampler's k-d order inside every part
@@ -693,14 +717,7 @@ int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride,
   // more than one 1024-thread workgroup per CU — more scenes are sampled chunk by chunk on the stream (launches of a stream do
   // not overlap), so that a single call cannot starve itself whatever `b` is.  (Two calls in flight on DIFFERENT streams are
   // still the caller's to bound: det6d_ops.h, ScenePipeline does it.)
-  static int cus = 0;
-  if (cus <= 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  const int chunk = std::max(8, cus / parts / 8 * 8);      // scenes per sampling launch (a multiple of 8: the block -> scene map)
+  const int chunk = cus / parts / 8 * 8;      // scenes per sampling launch (a multiple of 8: the block -> scene map); >= 8, checked above
   // DET6D_FPS_COOP_FAST=1: workgroup-scope publishing stores where the placement test and the handshake allow (see the top)
   static const int allow_fast = det6d_switch_int("DET6D_FPS_COOP_FAST", 0) ? 1 : 0;
   // (clamped like fps_seq.hip's: 0 would never advance a round, more than kCoopMaxPicks would write past the pick arrays in LDS)

@@ -693,7 +693,7 @@ DET6D_API int det6d_mlp_group3_supported(int c1, int c2, int c3, int ns, int com
 DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, const float *w1, int ldw1, const float *s1, int c1,
                                const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3, const float *s3,
                                int c3, const float *pts, int ldpts, const float *ctr, int ldctr, const int *idx, int n, int m,
-                               int ns, const int *cnt, const int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
+                               int ns, const int *cnt, int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
                                int col0, det6d_stream_t stream) {
   D6_GEMM_PRIO_HOST();
   if (rows < 0 || (rows & 31) || !p || !w1 || !w2 || !w3 || !s1 || !s2 || !s3 || !pts || !ctr || !y) return DET6D_EINVAL;
@@ -716,7 +716,7 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   // tiles by ticket on compact lists (hdr[10], hdr[11]: zeroed by the list builder and by the kernels themselves); the
   // experiments build keeps the static walk behind DET6D_GROUP_STATIC=1 for A/B runs
   static const int static_tiles = det6d_env_int("DET6D_GROUP_STATIC", 0);
-  g.ticket = (hdr && !static_tiles) ? const_cast<int *>(hdr) + 10 : nullptr;
+  g.ticket = (hdr && !static_tiles) ? hdr + 10 : nullptr;
   g.y = y; g.ldy = ldy; g.col0 = col0;
   static const int pre_entries = det6d_env_int("DET6D_GROUP_PRE", 1);
   g.pre = pre_entries;

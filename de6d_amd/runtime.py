@@ -607,11 +607,8 @@ class ScenePipeline(object):
         batch_size = batch_size * self.merge
         self.k = max(1, min(group, n_main))
         self.prefetch = prefetch
-        self.hw_queues = require_hw_queues((len(main_streams) if main_streams else n_main) +
-                                           (len(samplers) if samplers else sampler_streams), allow_aliasing)
-        self.main_streams = list(main_streams) if main_streams else [torch.cuda.Stream() for _ in range(n_main)]
-        self.sampler_streams = list(samplers) if samplers else [torch.cuda.Stream() for _ in range(sampler_streams)]
         from .ops import fused
+        n_samplers = len(samplers) if samplers else sampler_streams
         if fused.fps_is_cooperative(n_points):
             # The cooperative sampler of 32768 / 65536-point scenes needs ALL parts of a scene resident at once (they
             # poll each other).  Launches on different streams may be dispatched interleaved, so the launches in flight
@@ -620,7 +617,11 @@ class ScenePipeline(object):
             # launch the parts of a scene are consecutive in dispatch order).
             per_launch = min(group, n_main) * batch_size * (n_points // 16384)
             cus = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * COOP_CU_FRACTION)
-            self.sampler_streams = self.sampler_streams[:max(1, cus // max(1, per_launch))]
+            n_samplers = min(n_samplers, max(1, cus // max(1, per_launch)))
+        # the streams this pipeline will actually use (sampler streams counted AFTER the cooperative trim)
+        self.hw_queues = require_hw_queues((len(main_streams) if main_streams else n_main) + n_samplers, allow_aliasing)
+        self.main_streams = list(main_streams) if main_streams else [torch.cuda.Stream() for _ in range(n_main)]
+        self.sampler_streams = (list(samplers) if samplers else [torch.cuda.Stream() for _ in range(n_samplers)])[:n_samplers]
         n_main = len(self.main_streams)
         self.n_groups = max(1, n_main // self.k) + prefetch
         self.groups = []

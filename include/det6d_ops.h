@@ -95,7 +95,9 @@ int det6d_ball_query_pair(int b, int n, int m, float rin_a, float rout_a, int ns
  * in one lane with a sorted per-lane list, a centre with many takes a wave: a short LDS list with a pruning threshold,
  * ranked once at the end: the reference's ascending-index order either way).  workspace:
  * det6d_ball_query_grid_workspace_bytes(b, n) bytes, 16-byte aligned, caller owned.  ns_a, ns_b <= 64
- * (DET6D_EINVAL beyond: use det6d_ball_query_pair).  det6d_ball_query_grid_supported(n, ns_a, ns_b): 1 when this entry takes
+ * (DET6D_EINVAL beyond: use det6d_ball_query_pair).  idx_a (idx_b) must be 16-byte aligned when ns_a (ns_b) is a multiple of 4
+ * (index rows leave as 16-byte stores; DET6D_EINVAL otherwise, before anything is queued — an offset view of a larger buffer
+ * goes through det6d_ball_query_pair).  det6d_ball_query_grid_supported(n, ns_a, ns_b): 1 when this entry takes
  * the shape (the host asks before it routes a query here instead of through det6d_ball_query_pair / _cnt / _dilated, which
  * have no nsample limit, like the reference: ball_query_gpu.cu:53-130). */
 int det6d_ball_query_grid_supported(int n, int ns_a, int ns_b);
@@ -337,8 +339,14 @@ int det6d_mlp_group3_supported(int c1, int c2, int c3, int ns, int compact);
 int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, const float *w1, int ldw1, const float *s1, int c1,
                      const float *w2, int ldw2, const float *s2, int c2, const float *w3, int ldw3, const float *s3,
                      int c3, const float *pts, int ldpts, const float *ctr, int ldctr, const int *idx, int n, int m,
-                     int ns, const int *cnt, const int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
+                     int ns, const int *cnt, int *hdr, const int *crow_p, const int *crow_c, float *y, int ldy,
                      int col0, det6d_stream_t stream);
+/* `hdr` is NOT const: on compact lists the kernel draws its 32-row tiles from the ticket counter hdr[10] and counts its
+ * leaving workgroups in hdr[11] (both zero before and after every launch: the last workgroup to leave clears them, and so does
+ * det6d_compact_groups when it builds the list).  ONE launch at a time per list: two launches consuming the same list
+ * concurrently (two streams, parallel graph branches) would share the counter and skip or repeat tiles — give every launch
+ * in flight its own copy of the 16 header words (the row arrays crow_p / crow_c may be shared).  A launch that was aborted
+ * leaves the words undefined: rebuild the list or zero hdr[10..11] before reusing it. */
 
 /* First layer of a grouped MLP from per-point partial sums (csrc/expand.hip): with the chain order of gathered rows
  * (feature columns first, relative coordinates last) the feature part P[p][c] = chain_{k >= 3}(row_p[k] * W[k][c]) is one

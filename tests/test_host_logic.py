@@ -324,3 +324,20 @@ def test_hardware_queue_rule(monkeypatch):
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '24')
     with pytest.raises(RuntimeError):
         runtime.require_hw_queues(6)
+
+
+def test_whole_path_scalars_put_the_driver_timed_fraction_at_the_top_of_roofline():
+    """round-5 review item 6: roofline.frac is the DRIVER-TIMED whole-path fraction (algorithmic GFLOP per scene x value /
+    peak); the launch-by-launch family figures and the dominant launch become top-level scalars beside it; with clock
+    samples the fraction at the held clock is stated next to the nominal one"""
+    from bench_legs import whole_path_scalars, MFMA_F32_PEAK_TFLOPS
+    roof = {"frac": 0.659, "achieved": 103.7, "algorithmic_gflop_per_pass": 519.11, "saturated": {"frac": 0.736},
+            "dominant_launch": {"frac": 0.764}}
+    out = whole_path_scalars(roof, 80, 15009.82, {"sclk_mhz": 2200.0, "power_w": 1000.0})
+    assert out["family_frac_idle"] == 0.659 and out["family_frac_saturated"] == 0.736 and out["dominant_launch_frac"] == 0.764
+    assert abs(out["algorithmic_gflop_per_scene"] - 6.4889) < 1e-3
+    assert abs(out["achieved"] - 6.488875 * 15009.82 / 1e3) < 0.01
+    assert out["frac"] == out["whole_path_frac"] == round(out["achieved"] / MFMA_F32_PEAK_TFLOPS, 4) or abs(out["frac"] - 0.6192) < 2e-4
+    assert out["sclk_mhz"] == 2200.0 and out["power_w"] == 1000.0
+    assert abs(out["whole_path_frac_at_held_clock"] - out["frac"] * 2400.0 / 2200.0) < 1e-4
+    assert all(not isinstance(out[k], dict) for k in ("whole_path_frac", "family_frac_idle", "family_frac_saturated", "dominant_launch_frac"))

@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes shard scenes, run the (oracle) pipeline on
+"""The N > 1 path on CPU: world_size-2 and world_size-8 gloo processes shard scenes, run the (oracle) pipeline on
 their shard and merge detections with no data-path collective; plus the flat-bucket gradient
 all-reduce used only by the optional training step."""
 import os
@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -47,8 +48,9 @@ def _worker(rank, world, port, num_scenes, out_dir):
     lin.bias.grad = torch.full_like(lin.bias, float(10 * (rank + 1)))
     nred = parallel.allreduce_gradients(lin.parameters())
     assert nred == 15
-    assert torch.allclose(lin.weight.grad, torch.full_like(lin.weight, 1.5))
-    assert torch.allclose(lin.bias.grad, torch.full_like(lin.bias, 15.0))
+    mean_rank = (world + 1) / 2.0
+    assert torch.allclose(lin.weight.grad, torch.full_like(lin.weight, mean_rank))
+    assert torch.allclose(lin.bias.grad, torch.full_like(lin.bias, 10.0 * mean_rank))
     if rank == 0:
         np.save(os.path.join(out_dir, 'order.npy'), np.array([m['scene'] for m in merged]))
         np.save(os.path.join(out_dir, 'nbox.npy'), np.array([len(m['boxes']) for m in merged]))
@@ -64,9 +66,11 @@ def test_scene_shard_covers_all_scenes():
         assert set(sum(shards, [])) == set(range(num))
 
 
-def test_two_rank_gloo_sharding(tmp_path, oracle_ops):
-    num_scenes = 5
-    mp.spawn(_worker, args=(2, _free_port(), num_scenes, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world,num_scenes", [(2, 5), (8, 13)])
+def test_gloo_sharding(tmp_path, oracle_ops, world, num_scenes):
+    """world 2 / 5 scenes, and the shape the driver's 8-GPU node would run: 8 ranks / 13 scenes (two scenes per rank, the
+    last three slots wrap around to scenes 0..2 and are dropped by the merge)"""
+    mp.spawn(_worker, args=(world, _free_port(), num_scenes, str(tmp_path)), nprocs=world, join=True)
     order = np.load(os.path.join(str(tmp_path), 'order.npy'))
     np.testing.assert_array_equal(order, np.arange(num_scenes))
     assert np.load(os.path.join(str(tmp_path), 'nbox.npy')).shape == (num_scenes,)

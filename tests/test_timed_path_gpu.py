@@ -458,3 +458,54 @@ def test_sampler_failure_is_raised_by_finalize():
         fused.fps_status(b, n, ws)
     torch.cuda.synchronize()
     assert int(word) == 0
+
+
+@pytest.mark.parametrize("cfg_name,scene,b,n,shape", [
+    ('kitti_models/det6d_car.yaml', 'uniform', 8, 16384, dict(n_main=16, prefetch=4, sampler_streams=6, merge=10)),
+    ('kitti_models/det6d_car.yaml', 'beam', 8, 16384, dict(n_main=16, prefetch=4, sampler_streams=6, merge=10)),
+    ('synthetic_models/det6d_65536.yaml', 'uniform', 8, 65536, dict(n_main=4, prefetch=2, sampler_streams=6, merge=4)),
+])
+def test_the_regime_value_times_closed_loop_mid_stream_passes_vs_oracle(oracle_ops, cfg_name, scene, b, n, shape):
+    """round-5 review item 5: oracle parity IN the regime bench.py's `value` times, not transitively through the eager model.
+    ScenePipeline exactly as the bench builds it for 16384-point scenes (16 main + 6 sampler streams, 4 stages ahead, 80-scene
+    passes, closed loop) and for the 65536-point leg (4 main streams, 2 ahead, 32-scene passes), 48 passes in one stream on
+    both scene generators; four passes picked from the MIDDLE of the stream — every slot full, ticket-drawn tiles, samplers
+    and GEMMs of other passes on the chip — are cloned as they are delivered and compared with oracle/model.py bit for bit."""
+    from de6d_amd.runtime import load_config, build_model, ScenePipeline
+    from tests.util import beam_batch
+    cfg = load_config(cfg_name)
+    model = build_model(cfg, seed=1234, device='cuda')
+    merge = shape['merge']
+    make = beam_batch if scene == 'beam' else make_batch
+    n_inputs = 2 if n <= 16384 else 1                       # distinct resident pass inputs the slots cycle through
+    batches_np = [flat_points(make(6100 + 30 * j, b, n)) for j in range(n_inputs * merge)]
+    batches = [torch.from_numpy(p).cuda() for p in batches_np]
+    inputs = ScenePipeline.coalesce(batches, merge)
+    assert len(inputs) == n_inputs
+    pipe = ScenePipeline(model, b, n, group=1, points=inputs, **shape)
+    assert len(pipe.main_streams) == shape['n_main'] and pipe.n_groups == shape['n_main'] + shape['prefetch']
+    which = {id(r): i % n_inputs for i, r in enumerate(pipe.passes)}
+    n_passes = 48
+    picked = (17, 24, 25, 38)                              # passes of the stream (0-based), all with every slot in flight
+    got = {}
+
+    def on_done(step, r, preds):
+        p = step // merge
+        if p in picked:
+            got[step] = (which[id(r)], [{k: v.clone() for k, v in d.items()} for d in preds])
+    assert pipe.run(n_passes * merge, on_done=on_done) == n_passes * merge
+    torch.cuda.synchronize()
+    assert sorted(got) == [p * merge + j for p in picked for j in range(merge)]
+    refs = {}
+    for step in sorted(got):
+        inp, preds = got[step]
+        j = step % merge                                    # batch j of the pass's input
+        if (inp, j) not in refs:
+            refs[(inp, j)] = oracle_of(cfg, model, batches_np[inp * merge + j], b)['pred_dicts']
+        assert len(preds) == b
+        for g, w in zip(preds, refs[(inp, j)]):
+            np.testing.assert_array_equal(g['pred_boxes'].cpu().numpy(), w['pred_boxes'])
+            np.testing.assert_array_equal(g['pred_scores'].cpu().numpy(), w['pred_scores'])
+            np.testing.assert_array_equal(g['pred_labels'].cpu().numpy(), w['pred_labels'])
+    assert {inp for inp, _ in got.values()} == set(range(n_inputs))
+    assert sum(len(p['pred_scores']) for _, ps in got.values() for p in ps) > 0
