@@ -41,14 +41,16 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, experiments=False):
+def build(force=False, verbose=False, experiments=False, knobs=False):
     """experiments=True: a SEPARATE library (libdet6d_hip_experiments.so) compiled with -DDET6D_EXPERIMENTS, in which the
     tile-sweep / timing / stand-in environment variables of scripts/experiments are live.  The shipped library ignores them."""
-    objdir = os.path.join(CSRC, "build_experiments" if experiments else "build")
+    # knobs=True: a third library (libdet6d_hip_knobs.so, -DDET6D_KNOBS): the shipped kernels with the route / tile switches
+    # live and no instrumentation — the flavour A/B runs of routes are taken in (csrc/common.h)
+    objdir = os.path.join(CSRC, "build_experiments" if experiments else "build_knobs" if knobs else "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    flags = FLAGS + (["-DDET6D_EXPERIMENTS"] if experiments else [])
-    lib = LIB.replace(".so", "_experiments.so") if experiments else LIB
+    flags = FLAGS + (["-DDET6D_EXPERIMENTS"] if experiments else ["-DDET6D_KNOBS"] if knobs else [])
+    lib = LIB.replace(".so", "_experiments.so") if experiments else LIB.replace(".so", "_knobs.so") if knobs else LIB
 
     sources = SOURCES + (EXPERIMENT_SOURCES if experiments else [])
 
@@ -122,4 +124,4 @@ def _parse_usage(stderr):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv, knobs="--knobs" in sys.argv))

@@ -11,7 +11,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip.so")
-if os.environ.get("DET6D_EXPERIMENTS_LIB"):      # scripts/experiments only: the -DDET6D_EXPERIMENTS build (de6d_amd/_build.py)
+if os.environ.get("DET6D_KNOBS_LIB"):            # scripts only: the shipped kernels with the route switches live (-DDET6D_KNOBS)
+    LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip_knobs.so")
+elif os.environ.get("DET6D_EXPERIMENTS_LIB"):      # scripts/experiments only: the -DDET6D_EXPERIMENTS build (de6d_amd/_build.py)
     LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip_experiments.so")
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
@@ -131,7 +133,7 @@ _lib = None
 def experiment_switch(name, default=None):
     """value of an alternative-route variable (DET6D_NO_EXPAND, DET6D_COMPACT_SPLIT, ...) — honoured only together with
     DET6D_EXPERIMENTS_LIB=1, i.e. in the experiments build; the shipped configuration has ONE route per shape"""
-    if not os.environ.get("DET6D_EXPERIMENTS_LIB"):
+    if not (os.environ.get("DET6D_EXPERIMENTS_LIB") or os.environ.get("DET6D_KNOBS_LIB")):
         return default
     return os.environ.get(name, default)
 

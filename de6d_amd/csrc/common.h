@@ -49,9 +49,18 @@ static inline int det6d_switch_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 static inline bool det6d_switch_set(const char *name) { return getenv(name) != nullptr; }
-#ifdef DET6D_EXPERIMENTS
+// -DDET6D_KNOBS (python -m de6d_amd._build --knobs -> libdet6d_hip_knobs.so, loaded with DET6D_KNOBS_LIB=1): the SHIPPED kernels
+// with the det6d_env_* route / tile switches live and nothing else — no timers, statistics or debug hooks.  Round 6: an A/B
+// inside the experiments library said +10 % for two settings that are worth +0.5 % in the shipped one (its instrumented
+// one-pass group kernel is the slow side of that comparison); A/B runs of routes belong in this flavour.
+#if defined(DET6D_EXPERIMENTS) || defined(DET6D_KNOBS)
 static inline int det6d_env_int(const char *name, int dflt) { return det6d_switch_int(name, dflt); }
 static inline bool det6d_env_set(const char *name) { return det6d_switch_set(name); }
+#else
+static inline int det6d_env_int(const char *, int dflt) { return dflt; }
+static inline bool det6d_env_set(const char *) { return false; }
+#endif
+#ifdef DET6D_EXPERIMENTS
 #define D6_DBG_IS(v) (dbg == (v))
 // DET6D_DBG_POISON_LDS=<pattern>: fill the LDS of every CU before a sampler kernel (fps_seq.hip; tests only)
 void det6d_dbg_poison_lds_hook(hipStream_t stream);
@@ -72,8 +81,6 @@ void det6d_dbg_poison_lds_hook(hipStream_t stream);
 #define D6_GEMM_PRIO_DECL
 #define D6_GEMM_PRIO_APPLY() do {} while (0)
 #define D6_GEMM_PRIO_HOST() do {} while (0)
-static inline int det6d_env_int(const char *, int dflt) { return dflt; }
-static inline bool det6d_env_set(const char *) { return false; }
 #define D6_DBG_IS(v) false
 #endif
 

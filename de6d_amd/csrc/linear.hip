@@ -45,6 +45,13 @@ template <int BM, int BN, int WMW, int WNW, int TM, int TN, int BK = 16, int NBU
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void linear_kernel(const det6d_linear_args g) {
   D6_GEMM_PRIO_APPLY();
   constexpr bool FAST = FASTLVL >= 2;      // predicate-free buffer_load main loop
+  // PIPE (round 6): the steady-state slab as an explicit software pipeline.  The ISA of the FASTLVL = 2 loop showed the
+  // scheduler SINKING the next slab's four buffer loads below the slab's MFMAs (they left right before the closing barrier, and
+  // the next iteration opened with s_waitcnt vmcnt: a full L2 round trip exposed per slab, hidden only by the other workgroups
+  // of the CU), and every k-step as ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs (the LDS latency exposed eight times per slab).
+  // Now: the loads are pinned above the MFMA block (sched_barrier), and the fragments of k-step s + 1 are read while the MFMAs
+  // of k-step s run (two fragment sets in registers).
+  constexpr bool PIPE = FASTLVL >= 3;
   constexpr bool FAST_EPI = FASTLVL >= 1;  // predicate-free buffer_store epilogue on interior tiles (32-bit offsets)
   constexpr int LDA_S = BM + 2;  // +2 makes the transposing ds_write_b32 conflict-free (see below)
   constexpr int NA = BM / 64;    // A rows per thread
@@ -244,8 +251,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
   auto compute = [&](int buf) {
     const float *As = As_all + buf * BK * LDA_S;
     const float *Bs = Bs_all + buf * BK * BN;
+    if constexpr (PIPE) {
+      float af[2][TM], bf[2][TN];
+      auto frag = [&](int ks, float (&a_)[TM], float (&b_)[TN]) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) kstep(As, Bs, ks);
+        for (int i = 0; i < TM; ++i) a_[i] = As[(2 * ks + kh) * LDA_S + arow_s + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_[j] = Bs[(2 * ks + kh) * BN + bcol_s + 32 * j];
+      };
+      frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        if (ks + 1 < BK / 2) frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+      // issue order: the LDS reads of k-step s + 1 go out BEFORE the MFMAs of k-step s (left alone the scheduler puts them
+      // behind, into the same registers, and every k-step waits out the LDS latency)
+      constexpr int NRD = (TM + 1) / 2 + (TN + 1) / 2;      // ds_read2_b32 pairs the fragments' two 32-row blocks
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        if (ks + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) kstep(As, Bs, ks);
+    }
   };
   // A short last slab (K = 68, 132, 260: [xyz | C | pad] rows) is peeled out of the main loop and issues
   // only the k-steps that hold data; the skipped steps would multiply zeros, so every output's chain
@@ -327,6 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         store_tile(0);
         __syncthreads();
         load_tile_fast(k0 + BK);
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);     // the loads stay above the MFMA block
         compute(0);
         __syncthreads();
       }
@@ -351,6 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
     if (FAST) {
       for (; k0 + 2 * BK <= K; k0 += BK) {
         load_tile_fast(k0 + BK);
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         store_tile(buf ^ 1);
         __syncthreads();
@@ -659,9 +697,18 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
   static const int n64_env = det6d_env_int("DET6D_LINEAR_N64MAX", -1);
   const int force_k_max = k64_env >= 0 ? k64_env : (a->hdr ? 512 : 0);
   static const bool fast64 = (det6d_env_int("DET6D_LINEAR_FAST64", 0) != 0);
+  static const int pipe = det6d_env_int("DET6D_LINEAR_PIPE", 1);            // round 6: software-pipelined slab (FASTLVL 3): 596 -> 580 us over the four plain GEMMs of an 80-scene pass
   static const bool nbuf2 = det6d_env_set("DET6D_LINEAR_NBUF2");   // double-buffered LDS tiles, one barrier per slab
   static const int bk32 = det6d_env_int("DET6D_LINEAR_BK32", 0);   // K from which BK = 32 is used
   const int force_n_max = n64_env >= 0 ? n64_env : (a->hdr ? 1024 : 512);
+  // Round 6: a grid of 128 x 128 tiles that leaves the CUs with 2.5 workgroups each (the head's shared FC over the 20480 rows of
+  // an 80-scene pass: 160 x 4 = 640 workgroups on 256 CUs) runs three rounds where two and a half would do; 128 x 64 tiles make
+  // it 5 per CU: 270.9 -> 242.8 us per launch replayed back to back (119 -> 133 TFLOP/s, scripts/r06/gpu_t8.sh).  Only long K
+  // loops gain (SA3's aggregation FC, 640 workgroups as well but K = 512, does not), so the rule asks for K >= 1024.
+  static const int balance_env = det6d_env_int("DET6D_LINEAR_BALANCE64", 1);
+  const int wg128 = gm_cap * det6d_divup(a->ncols, 128);
+  const bool balance64 = balance_env && !a->hdr && a->k >= 1024 && a->ncols >= 128 && (a->ncols & 127) == 0 && wg128 >= 256 && wg128 < 1024 &&
+                         (wg128 % 256) != 0 && ((2 * wg128) % 256) == 0;
   if (a->ncols > 64) {
     // few row tiles (the FC layers over 256..1024 centres per scene): 64x64 tiles spread the K loop
     // over all CUs instead of leaving most of the chip idle behind a handful of 128x128 tiles.  These
@@ -675,15 +722,20 @@ DET6D_API int det6d_linear(const det6d_linear_args *a, det6d_stream_t stream) {
         hipLaunchKernelGGL((linear_kernel<64, 64, 2, 2, 1, 1, 16, 1, 1>), dim3(det6d_divup(a->rows, 64) * det6d_divup(a->ncols, 64)),
                            dim3(256), 0, s, *a);
     }
-    else if (a->ncols <= force_n_max && a->k <= force_k_max)
+    else if ((a->ncols <= force_n_max && a->k <= force_k_max) || balance64) {
       // 128x64 tiles (5 waves/SIMD) used to win 2-7 % on short K loops; with the vector-ALU-free main loop
       // and epilogue the 128x128 tile is ahead everywhere (GEMM family 1.921 -> 1.906 ms), so this branch is
       // off by default (DET6D_LINEAR_K64MAX = largest K that still takes it)
-      hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm_cap * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
-    else if (nbuf2)
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
-    else if (bk32 && a->k >= bk32)
-      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      if (pipe) hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1, 16, 1, 3>), dim3(gm_cap * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+      else hipLaunchKernelGGL((linear_kernel<128, 64, 2, 2, 2, 1>), dim3(gm_cap * det6d_divup(a->ncols, 64)), dim3(256), 0, s, *a);
+    } else if (nbuf2) {
+      if (pipe) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2, 3>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 2>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+    } else if (bk32 && a->k >= bk32) {
+      if (pipe) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32, 1, 3>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+      else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 32>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
+    } else if (pipe)
+      hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2, 16, 1, 3>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
     else
       hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 2, 2>), dim3(gm_cap * det6d_divup(a->ncols, 128)), dim3(256), 0, s, *a);
   } else if (a->ncols > 32) {

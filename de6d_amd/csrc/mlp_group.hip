@@ -180,8 +180,9 @@ __device__ int d6_group_kmul = 1;
 // phase timers of mlp_group_kernel<256, 512, 1024> (100 MHz wall clock as seen by wave 0 of every workgroup, summed):
 // [0] layer 1 incl. its barrier, [1] layer 2 K loop, [2] layer 2 epilogue + barrier, [3] layer 3 K loop, [4] pooling / stores,
 // [5] tiles, [6] whole kernel, [7] workgroups
+__device__ int d6_group_phase_c2 = 512, d6_group_phase_c3 = 1024;   // which instantiation is timed (DET6D_GROUP_PHASE_C2 / _C3)
 __device__ unsigned long long d6_group_phase[8 + 18];   // [8] shader-clock cycles of the kernel (wave 0), [9] .. K-loop wall time of layer 3 by wave (8) and of layer 2 by wave (8), [25] unused
-#define D6_PHASE_DECL const unsigned long long ph_c0 = clock64(); unsigned long long ph_w3 = 0, ph_w2 = 0, ph_wt = 0; unsigned long long ph_t = wall_clock64(), ph_acc[5] = {0, 0, 0, 0, 0}, ph_tiles = 0; const unsigned long long ph_start = ph_t; const bool ph_on = C3 == 1024;
+#define D6_PHASE_DECL const unsigned long long ph_c0 = clock64(); unsigned long long ph_w3 = 0, ph_w2 = 0, ph_wt = 0; unsigned long long ph_t = wall_clock64(), ph_acc[5] = {0, 0, 0, 0, 0}, ph_tiles = 0; const unsigned long long ph_start = ph_t; const bool ph_on = C3 == d6_group_phase_c3 && C2 == d6_group_phase_c2;
 #define D6_PHASE(i) do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = wall_clock64(); ph_acc[i] += now_ - ph_t; ph_t = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define D6_WAVE_T0 do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); ph_wt = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define D6_WAVE_T1(x) do { if (ph_on) { __builtin_amdgcn_sched_barrier(0); x += wall_clock64() - ph_wt; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
   int *tags = reinterpret_cast<int *>(Y1 + 32 * LDY);             // 2 x 32 row tags, by tile parity
   int it = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
-  float *scr = reinterpret_cast<float *>(tags + 64) + wave * (64 * 4);                      // wave-private: g_store_group
+  float *scr = reinterpret_cast<float *>(tags + 64) + wave * (64 * (TN3 >= 4 ? 4 : TN3));   // wave-private: g_store_group
   const int live_tiles = (COMPACT ? g.hdr[0] : g.rows) / 32;
   if ((int)blockIdx.x >= live_tiles) return;
   int h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
@@ -634,10 +635,13 @@ __global__ __launch_bounds__(256, 2) void mlp_group_stream_kernel(const GroupArg
 
 template <int C1, int C2, int C3, bool COMPACT>
 int launch_group_stream(const GroupArgs &g, hipStream_t stream) {
-  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64 + 4 * 64 * 4);   // + tags + store scratch
+  constexpr int kVW3 = (C3 / 128) >= 4 ? 4 : (C3 / 128);
+  const size_t lds_bytes = sizeof(float) * (32 * (size_t)(C1 + 1 + 2 * 129) + 64 + 4 * 64 * kVW3);   // + tags + store scratch
   DET6D_MAX_DYNAMIC_LDS((mlp_group_stream_kernel<C1, C2, C3, COMPACT>), lds_bytes);
+  int per_cu = (int)((160 * 1024) / lds_bytes);      // 2 for the head's groups (66 KB), 3 for SA3's (52 KB)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
   int blocks = g.rows / 32;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   hipLaunchKernelGGL((mlp_group_stream_kernel<C1, C2, C3, COMPACT>), dim3(blocks), dim3(256), lds_bytes, stream, g);
   return det6d_check_launch("det6d_mlp_group3 (streaming)");
 }
@@ -657,6 +661,13 @@ int launch_group(const GroupArgs &g, hipStream_t stream) {
   int blocks = g.rows / 32;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
 #ifdef DET6D_EXPERIMENTS
+  static bool phase_set = false;
+  if (!phase_set) {
+    const int pc2 = det6d_env_int("DET6D_GROUP_PHASE_C2", 512), pc3 = det6d_env_int("DET6D_GROUP_PHASE_C3", 1024);
+    hipMemcpyToSymbol(HIP_SYMBOL(d6_group_phase_c2), &pc2, sizeof(int));
+    hipMemcpyToSymbol(HIP_SYMBOL(d6_group_phase_c3), &pc3, sizeof(int));
+    phase_set = true;
+  }
   static const int whatif = det6d_env_int("DET6D_GROUP_WHATIF", 0);
   static bool whatif_set = false;
   if (whatif && !whatif_set) {
@@ -731,19 +742,29 @@ DET6D_API int det6d_mlp_group3(int rows, const float *p, int ldp, int pcol0, con
   // ahead of the producing phase (12.98 vs 12.87 k scenes/s, ray-cast scenes 6.06 vs 6.09 k).  Narrow group (default):
   // its one-pass form holds 143 registers with eight waves, i.e. one workgroup per CU; the streaming form runs it 8-10 %
   // faster with the chip full (196 -> 180 us, ray-cast scenes 446 -> 400 us) and the pipeline gains 0.5-0.7 %.
-  static const int stream_form = det6d_env_int("DET6D_GROUP_STREAM", 2);
+  // Round 6, at the 80-scene pass size the bench runs since round 5: in the EXPERIMENTS build the streaming form of the wide
+  // group and eight waves per tile for SA3's [128 -> 256 -> 256] group looked like +4.3 % / +5.2 % / together +10.3 %
+  // (scripts/r06/gpu_t4.sh) — an artefact: that build's one-pass kernels carry phase timers.  The same A/B in the KNOBS build
+  // (the shipped kernels with the switches live, scripts/r06/gpu_t6.sh, interleaved, two repeats): round-5 settings 15 034
+  // scenes/s; wide group streaming 15 171 (+0.9 %); SA3 with eight waves 14 732 (-2.0 %); SA3's wide group streaming too (mask
+  // 7) 15 114; pipelined linear slab 15 138 (+0.7 %).  Default: mask 3, SA3 stays at four waves.
+  static const int stream_form = det6d_env_int("DET6D_GROUP_STREAM", 3);
   if ((stream_form & 1) && c1 == 256 && c2 == 512 && c3 == 1024)
     return compact ? launch_group_stream<256, 512, 1024, true>(g, s) : launch_group_stream<256, 512, 1024, false>(g, s);
   if ((stream_form & 2) && c1 == 256 && c2 == 256 && c3 == 512)
     return compact ? launch_group_stream<256, 256, 512, true>(g, s) : launch_group_stream<256, 256, 512, false>(g, s);
+  if ((stream_form & 4) && c1 == 128 && c2 == 256 && c3 == 256)      // SA3's wide group (three workgroups per CU)
+    return compact ? launch_group_stream<128, 256, 256, true>(g, s) : launch_group_stream<128, 256, 256, false>(g, s);
 #define D6_GROUP(A, B, C, NWD)                                                                        \
   if (c1 == A && c2 == B && c3 == C) {                                                                \
     if ((nw_env ? nw_env : NWD) == 8 && B >= 256)                                                     \
       return compact ? launch_group<A, B, C, true, (B >= 256 ? 8 : 4)>(g, s) : launch_group<A, B, C, false, (B >= 256 ? 8 : 4)>(g, s); \
     return compact ? launch_group<A, B, C, true, 4>(g, s) : launch_group<A, B, C, false, 4>(g, s);    \
   }
+  static const int sa3_waves = det6d_env_int("DET6D_GROUP_SA3_WAVES", 4);      // knobs build: 8 = eight waves per tile (slower: see below)
   D6_GROUP(128, 128, 256, 4)
-  D6_GROUP(128, 256, 256, 4)
+  if (sa3_waves != 8) { D6_GROUP(128, 256, 256, 4) }
+  D6_GROUP(128, 256, 256, 8)
   D6_GROUP(256, 256, 512, 8)
   D6_GROUP(256, 512, 1024, 8)
 #undef D6_GROUP

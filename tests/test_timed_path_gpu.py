@@ -492,7 +492,9 @@ def test_the_regime_value_times_closed_loop_mid_stream_passes_vs_oracle(oracle_o
     def on_done(step, r, preds):
         p = step // merge
         if p in picked:
-            got[step] = (which[id(r)], [{k: v.clone() for k, v in d.items()} for d in preds])
+            # host copies, taken NOW: the slot is relaunched on its own stream as soon as this returns (a device-side clone on
+            # the default stream would race with that launch)
+            got[step] = (which[id(r)], [{k: v.cpu() for k, v in d.items()} for d in preds])
     assert pipe.run(n_passes * merge, on_done=on_done) == n_passes * merge
     torch.cuda.synchronize()
     assert sorted(got) == [p * merge + j for p in picked for j in range(merge)]
