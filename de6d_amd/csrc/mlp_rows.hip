@@ -329,6 +329,230 @@ __global__ __launch_bounds__(256) void mlp_rows_resident_kernel(const RowsArgs g
   }
 }
 
+
+// ---- round 6: the same SA1-shaped stack with WAVE-PRIVATE 32-row tiles -------------------------------------------------------
+// mlp_rows_resident_kernel above still crosses three workgroup barriers per 64-row tile with its four waves specialised by
+// layer (layer 1 runs on two waves, layer 2 on the other two while the rest wait): 98 us per 80-scene launch against a matrix
+// floor of 38.  Here a wave owns a 32-row tile through all three layers and never waits for another wave: eight waves per CU
+// (two workgroups of four) sit at eight different points of their tiles, so the matrix pipes see MFMAs from one wave while the
+// other loads, stores or reads LDS.  Layer 0's B fragments (both column tiles, K0 registers) stay in registers for the life
+// of the persistent wave, the small layers' weights in LDS (staged once per workgroup: the only workgroup barrier), the next
+// tile's input rows are requested right after the current tile's have been written to LDS, and ONE wave-private LDS buffer of
+// 32 x (K0 + 1) floats holds in turn the input, layer 0's output and layer 1's output (a layer's accumulators stay in registers
+// until its last A fragment has been read; LDS serves a wave's instructions in order).  Same MFMA chain per output element:
+// bit-identical to the other two kernels.
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(256, 2) void mlp_rows_wave_kernel(const RowsArgs g) {
+  D6_GEMM_PRIO_APPLY();
+  static_assert(K0 % 32 == 0 && K1 == 64 && K2 == 32, "SA1-shaped stacks: two column tiles, then one, then one");
+  constexpr int LD0 = K0 + 1, LD1 = K1 + 1, LD2 = K2 + 1;
+  constexpr int Q = K0 / 4;                          // float4 per input row
+  // input tile = 4 blocks of 8 rows; a block's 8 Q float4 are dealt lane + 64 j (j < NJ): the (row, quad) a lane holds is the
+  // same in every block, so its byte offsets are computed ONCE and a block / a tile only moves a scalar offset
+  constexpr int NJ = 8 * Q / 64;
+  static_assert(8 * Q % 64 == 0, "eight input rows fill whole wave-instructions");
+  extern __shared__ float lds[];
+  float *W1s = lds;                                  // K1 x 32 (layer 1's weights, k-major)
+  float *W2s = lds + K1 * 32;                        // K2 x 32 (layer 2's, columns >= n zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  float *X = lds + (K1 + K2) * 32 + wave * (32 * LD0);      // wave-private
+  const det6d_rows_layer &L0 = g.layers[0][0], &L1 = g.layers[0][1], &L2 = g.layers[0][2];
+  for (int t = tid; t < K1 * 32; t += 256) {
+    const int k = t >> 5, c = t & 31;
+    W1s[t] = c < L1.n ? L1.w[(size_t)(L1.wrow0 + k) * L1.ldw + c] : 0.f;
+  }
+  for (int t = tid; t < K2 * 32; t += 256) {
+    const int k = t >> 5, c = t & 31;
+    W2s[t] = c < L2.n ? L2.w[(size_t)(L2.wrow0 + k) * L2.ldw + c] : 0.f;
+  }
+  // layer 0's B fragments: k-step s, column tile j: W0[2 s + kh][32 j + l31]
+  float b0[2][K0 / 2];
+  {
+    const __amdgpu_buffer_rsrc_t srd0 =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(L0.w + (size_t)L0.wrow0 * L0.ldw), 0, (unsigned)((size_t)L0.k * L0.ldw * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t voff = (uint32_t)(kh * L0.ldw + 32 * j + l31) * 4u;
+#pragma unroll
+      for (int u = 0; u < K0 / 2; ++u)
+        b0[j][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd0, voff, 2 * u * L0.ldw * 4, 0));
+    }
+  }
+  float sh0[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) sh0[j] = L0.shift ? L0.shift[32 * j + l31] : 0.f;
+  const bool cok1 = l31 < L1.n, cok2 = l31 < L2.n;
+  const float sh1 = (cok1 && L1.shift) ? L1.shift[l31] : 0.f;
+  const float sh2 = (cok2 && L2.shift) ? L2.shift[l31] : 0.f;
+  __syncthreads();                                   // W1s / W2s staged: the only workgroup barrier
+
+  // every tile is whole (the launcher asks for rows % 32 == 0) and every buffer is addressed with 32-bit byte offsets
+  const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)(g.x + g.xcol0), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_y0 = __builtin_amdgcn_make_buffer_rsrc((void *)(L0.out ? L0.out + L0.ocol0 : g.x), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_y1 = __builtin_amdgcn_make_buffer_rsrc((void *)(L1.out ? L1.out + L1.ocol0 : g.x), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_y2 = __builtin_amdgcn_make_buffer_rsrc((void *)(L2.out + L2.ocol0), 0, 0xffffffff, 0x00020000);
+  uint32_t xin[NJ], xls[NJ];                         // per lane: byte offset of its float4 in the rows / in the LDS image
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = lane + 64 * j, row = f / Q, q = f % Q;
+    xin[j] = (uint32_t)(row * g.ldx + 4 * q) * 4u;
+    xls[j] = (uint32_t)(row * LD0 + 4 * q);
+  }
+  const bool out0 = L0.out != nullptr, out1 = L1.out != nullptr;
+  const bool relu0 = L0.act == 1, relu1 = L1.act == 1, relu2 = L2.act == 1;
+  const int ldo0 = L0.ldo * 4, ldo1 = L1.ldo * 4, ldo2 = L2.ldo * 4, ldx8 = g.ldx * 32;     // bytes (ldx8: eight input rows)
+
+  const int ntiles = g.rows / 32;
+  const int stride = gridDim.x * 4;
+  f32x4r nxt[4][NJ];
+  auto gload = [&](const int tile) {
+    const int s0 = tile * 4 * ldx8;
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        nxt[bq][j] = __builtin_bit_cast(f32x4r, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xin[j], s0 + bq * ldx8, 0));
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) gload(tile);
+  for (; tile < ntiles; tile += stride) {
+    // ---- input rows -> X (row stride LD0); the previous tile's last reads of X were issued before these writes ----
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float *dst = X + xls[j] + bq * 8 * LD0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = nxt[bq][j][e];
+      }
+    if (tile + stride < ntiles) gload(tile + stride);            // in flight during this tile's three layers
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): the tile is in LDS (this wave wrote all of it)
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 0: two column tiles share every A fragment ----
+    f32x16 a0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a0[j][e] = 0.f;
+    {
+      const float *xa = X + l31 * LD0 + kh;
+#pragma unroll
+      for (int blk = 0; blk < K0 / 32; ++blk) {
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = xa[32 * blk + 2 * u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          a0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[0][16 * blk + u], a0[0], 0, 0, 0);
+          a0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[1][16 * blk + u], a0[1], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                             // (every read of the input is issued: X may be rewritten)
+    const uint32_t vrow = (uint32_t)(tile * 32 + 4 * kh);        // first row of this lane's accumulator registers
+    // (activation and store switches are wave-uniform: one scalar branch per tile each, none per element)
+    if (relu0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a0[j][e] = d6_relu(a0[j][e] + sh0[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a0[j][e] = a0[j][e] + sh0[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float *xw = X + (4 * kh) * LD1 + 32 * j + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xw[((e & 3) + 8 * (e >> 2)) * LD1] = a0[j][e];
+    }
+    if (out0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t voff = vrow * (uint32_t)ldo0 + (uint32_t)(32 * j + l31) * 4u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          // (a local copy: __builtin_bit_cast straight on the vector ELEMENT stored element 0 sixteen times — seen in the ISA)
+          const float v = a0[j][e];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd_y0, voff, ((e & 3) + 8 * (e >> 2)) * ldo0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 1 ----
+    f32x16 a1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a1[e] = 0.f;
+    {
+      const float *xa = X + l31 * LD1 + kh;
+      const float *wb = W1s + kh * 32 + l31;
+#pragma unroll
+      for (int blk = 0; blk < K1 / 32; ++blk) {
+        float a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a[u] = xa[32 * blk + 2 * u]; b[u] = wb[(32 * blk + 2 * u) * 32]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], a1, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (relu1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a1[e] = d6_relu(a1[e] + sh1);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a1[e] = a1[e] + sh1;
+    }
+    {
+      float *xw = X + (4 * kh) * LD2 + l31;          // (L1.n == K2 == 32: every column is a real one)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xw[((e & 3) + 8 * (e >> 2)) * LD2] = a1[e];
+    }
+    if (out1 && cok1) {
+      const uint32_t voff = vrow * (uint32_t)ldo1 + (uint32_t)l31 * 4u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = a1[e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd_y1, voff, ((e & 3) + 8 * (e >> 2)) * ldo1, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 2 ----
+    f32x16 a2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a2[e] = 0.f;
+    {
+      const float *xa = X + l31 * LD2 + kh;
+      const float *wb = W2s + kh * 32 + l31;
+      float a[16], b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { a[u] = xa[2 * u]; b[u] = wb[(2 * u) * 32]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], a2, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (relu2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a2[e] = d6_relu(a2[e] + sh2);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a2[e] = a2[e] + sh2;
+    }
+    if (cok2) {
+      const uint32_t voff = vrow * (uint32_t)ldo2 + (uint32_t)l31 * 4u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = a2[e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd_y2, voff, ((e & 3) + 8 * (e >> 2)) * ldo2, 0);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Validates a stack description and derives the LDS plan: k0 (input width), wa / wb (row widths of the two activation
@@ -397,7 +621,21 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   g.vec4 = ((k0 & 3) == 0 && (ldx & 3) == 0 && (xcol0 & 3) == 0 && (((uintptr_t)x) & 15) == 0) ? 1 : 0;
   if (rows == 0) return DET6D_OK;
   // the first level's stack ([96 -> 64 -> 32 -> 1] over 4096 centres per scene): weights resident in registers
-  static const int resident_env = det6d_env_int("DET6D_ROWS_RESIDENT", 1);      // experiments build: 0 = the general kernel
+  static const int resident_env = det6d_env_int("DET6D_ROWS_RESIDENT", 2);
+  // DET6D_ROWS_RESIDENT (knobs build): 2 (default) = wave-private tiles (round 6), 1 = the four-wave resident kernel of round 5,
+  // 0 = the general kernel
+  // (whole tiles only, 32-bit byte offsets into the input and the three outputs)
+  bool fits32 = (size_t)rows * ldx * 4 < 0xfff00000ull;
+  for (int l = 0; l < 3 && nlayers[0] == 3; ++l) fits32 = fits32 && (!layers[l].out || (size_t)rows * layers[l].ldo * 4 < 0xfff00000ull);
+  if (resident_env == 2 && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && (rows & 31) == 0 && fits32 &&
+      layers[0].k == 96 && layers[0].n == 64 && layers[1].n == 32 && layers[2].n <= 32 && layers[0].ldw >= 64 && layers[1].ldw >= 32) {
+    constexpr size_t lds_wave = sizeof(float) * ((64 + 32) * 32 + 4 * 32 * 97);
+    DET6D_MAX_DYNAMIC_LDS((mlp_rows_wave_kernel<96, 64, 32>), lds_wave);
+    int blocks = ((rows + 31) / 32 + 3) / 4;
+    if (blocks > 512) blocks = 512;                  // two workgroups of four independent waves per CU, persistent over the tiles
+    hipLaunchKernelGGL((mlp_rows_wave_kernel<96, 64, 32>), dim3(blocks), dim3(256), lds_wave, (hipStream_t)stream, g);
+    return det6d_check_launch("det6d_mlp_rows");
+  }
   if (resident_env && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && layers[0].k == 96 &&
       layers[0].n == 64 && layers[1].n == 32 && layers[2].n <= 32 && layers[0].ldw >= 64 && layers[1].ldw >= 32) {
     constexpr size_t lds_resident = sizeof(float) * (2 * 64 * 97 + 64 * 65);
