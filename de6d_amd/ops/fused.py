@@ -442,7 +442,7 @@ def nms_device(boxes, thresh, normal=False):
 
 
 #: point count from which the grid-hashed search replaces the brute-force sweep
-GRID_QUERY_MIN_N = 2048
+GRID_QUERY_MIN_N = int(L.experiment_switch('DET6D_GRID_MIN_N', '2048'))
 
 
 def ball_query_pair(xyz, new_xyz, shell_a, shell_b, grid=None):
