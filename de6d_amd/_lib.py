@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip.so")
 if os.environ.get("DET6D_KNOBS_LIB"):            # scripts only: the shipped kernels with the route switches live (-DDET6D_KNOBS)
     LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip_knobs.so")
+    if os.environ["DET6D_KNOBS_LIB"].endswith(".so"):      # an A/B against another BUILD of the library (scripts/r06/gpu_t14.sh)
+        LIB_PATH = os.environ["DET6D_KNOBS_LIB"]
 elif os.environ.get("DET6D_EXPERIMENTS_LIB"):      # scripts/experiments only: the -DDET6D_EXPERIMENTS build (de6d_amd/_build.py)
     LIB_PATH = os.path.join(_HERE, "csrc", "libdet6d_hip_experiments.so")
 

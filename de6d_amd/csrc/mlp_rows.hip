@@ -23,10 +23,55 @@ struct RowsArgs {
   const float *x; int ldx; int xcol0; int k0;     // input: columns [xcol0, xcol0 + k0) of x (rows, ldx)
   int wa, wb;                                     // LDS row widths: XA holds the input and the outputs of odd layers, XB the outputs of even layers
   int vec4;                                       // input rows are 16-byte aligned and k0 % 4 == 0
+  int fits32;                                     // every output buffer is addressable with 32-bit byte offsets
   int kchunk;                                     // columns of the input held in LDS at a time (== k0: all of them)
   int nlayers[2];
   det6d_rows_layer layers[2][kMaxLayers];         // chain c = blockIdx.y
 };
+
+// Epilogue of one 32 x 32 accumulator tile of a plain layer: + shift, activation, the tile into the next layer's LDS image
+// (`Y`, row stride LDY; nullptr for the last layer) and / or into the layer's output rows.  Round 6: the per-element form
+// (`if (!last && cok) .. if (L.out && cok && r < rows) ..` with a 64-bit address per element) cost ~25 scalar / vector
+// instructions per accumulator register — several times the MFMAs of a narrow layer; now the activation and store switches
+// are wave-uniform branches around whole loops, and an INTERIOR tile (all 32 rows and all 32 columns live, 32-bit byte
+// offsets) stores through the buffer path with the row of every accumulator register as a scalar offset.
+__device__ __forceinline__ void rows_epilogue(f32x16 &acc, const det6d_rows_layer &L, const float sh, const int col, float *__restrict__ Y,
+                                              const int LDY, const int rb_row0, const int kh, const int row_g0, const int rows,
+                                              const bool fits32) {
+  const bool cok = col < L.n;
+  if (L.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = d6_relu(acc[e] + sh);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = acc[e] + sh;
+  }
+  if (Y != nullptr && cok) {
+    float *yw = Y + (rb_row0 + 4 * kh) * LDY + col;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) yw[((e & 3) + 8 * (e >> 2)) * LDY] = acc[e];
+  }
+  if (L.out == nullptr) return;
+  const int c0 = col & ~31;
+  const bool interior = fits32 && row_g0 + rb_row0 + 32 <= rows && c0 + 32 <= L.n;      // wave-uniform
+  if (interior) {
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)(L.out + L.ocol0), 0, 0xffffffff, 0x00020000);
+    const int ldo4 = L.ldo * 4;
+    const uint32_t voff = (uint32_t)(row_g0 + rb_row0 + 4 * kh) * (uint32_t)ldo4 + (uint32_t)col * 4u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = acc[e];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd, voff, ((e & 3) + 8 * (e >> 2)) * ldo4, 0);
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int r = row_g0 + rb_row0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+    const float v = acc[e];
+    if (cok && r < rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
+  }
+}
 
 // RB = 32-row blocks per tile.  RB = 2 (narrow stacks: at most two column tiles per layer, e.g. [96 -> 64 -> 32 -> 1]): the
 // work items of a layer are (row block, column tile) pairs, so that a layer of two column tiles keeps all four waves busy
@@ -45,6 +90,22 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
   const int ntiles_rows = (g.rows + TR - 1) / TR;
   constexpr int TPR = 8 / RB;                     // threads per row of the input tile
   const int lrow = tid / TPR, lq = tid % TPR;
+  // next-tile input prefetch (whole-input stacks with 16-byte rows whose float4 deal evenly over the row's threads)
+  constexpr int kPre = 8;
+  const int nv = g.k0 / (4 * TPR);
+  const bool pre = !CHUNKED && g.vec4 && nv * 4 * TPR == g.k0 && nv <= kPre;
+  f32x4r nxt[kPre];
+  auto gfetch = [&](const int t) {
+    const int r = t * TR + lrow;
+    const float *src = g.x + (size_t)(r < g.rows ? r : 0) * g.ldx + g.xcol0 + 4 * lq;
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+      if (i < nv) {
+        nxt[i] = *reinterpret_cast<const f32x4r *>(src + 4 * TPR * i);
+        if (r >= g.rows) nxt[i] = f32x4r{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  if (pre && (int)blockIdx.x < ntiles_rows) gfetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles_rows; tile += gridDim.x) {
     // ---- input tile (columns [c0, c0 + kchunk)) -> XA (rows past the end: zeros); 8 threads per row, 16 bytes each where
     // the rows allow it ----
@@ -63,7 +124,20 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
         for (int c = lq; c < kw; c += TPR) dst[c] = r < g.rows ? src[c] : 0.f;
       }
     };
-    load_input(0);
+    if (pre) {
+      // (round 6) the tile's rows were requested a tile ago (registers): LDS image now, the NEXT tile's rows requested before
+      // the first layer, in flight during all of this tile's layers
+      float *dst = XA + lrow * LDA;
+#pragma unroll
+      for (int i = 0; i < kPre; ++i)
+        if (i < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * lq + 4 * TPR * i + e] = nxt[i][e];
+        }
+      if (tile + (int)gridDim.x < ntiles_rows) gfetch(tile + gridDim.x);
+    } else {
+      load_input(0);
+    }
     for (int l = 0; l < nl; ++l) {
       const det6d_rows_layer &L = g.layers[chain][l];
       const float *X = (l & 1) ? XB : XA;
@@ -132,17 +206,8 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
           }
         }
         if (mine) {
-          const bool cok = col < L.n;
-          const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
-            float v = acc[e] + sh;
-            if (L.act == 1) v = d6_relu(v);
-            if (!last && cok) Y[row * LDY + col] = v;
-            const int r = tile * 32 + row;
-            if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
-          }
+          const float sh = (col < L.n && L.shift) ? L.shift[col] : 0.f;
+          rows_epilogue(acc, L, sh, col, last ? nullptr : Y, LDY, 0, kh, tile * 32, g.rows, g.fits32 != 0);
         }
         continue;
       }
@@ -185,17 +250,8 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs g) {
         }
         if (blk < nblk) compute(bs[0], blk);           // nblk mod 3 blocks left: sets 0, 1 hold them
         if (blk + 1 < nblk) compute(bs[1], blk + 1);
-        const bool cok = col < L.n;
-        const float sh = (cok && L.shift) ? L.shift[col] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          float v = acc[e] + sh;
-          if (L.act == 1) v = d6_relu(v);
-          if (!last && cok) Y[row * LDY + col] = v;
-          const int r = tile * TR + row;
-          if (L.out && cok && r < g.rows) L.out[(size_t)r * L.ldo + L.ocol0 + col] = v;
-        }
+        const float sh = (col < L.n && L.shift) ? L.shift[col] : 0.f;
+        rows_epilogue(acc, L, sh, col, last ? nullptr : Y, LDY, 32 * rb, kh, tile * TR, g.rows, g.fits32 != 0);
       }
     }
     __syncthreads();     // the next tile's input overwrites XA, which the last layer may still be reading
@@ -624,9 +680,14 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
   static const int resident_env = det6d_env_int("DET6D_ROWS_RESIDENT", 2);
   // DET6D_ROWS_RESIDENT (knobs build): 2 (default) = wave-private tiles (round 6), 1 = the four-wave resident kernel of round 5,
   // 0 = the general kernel
-  // (whole tiles only, 32-bit byte offsets into the input and the three outputs)
+  // (32-bit byte offsets into the input and every output: the buffer-store epilogues and the wave-private kernel)
   bool fits32 = (size_t)rows * ldx * 4 < 0xfff00000ull;
-  for (int l = 0; l < 3 && nlayers[0] == 3; ++l) fits32 = fits32 && (!layers[l].out || (size_t)rows * layers[l].ldo * 4 < 0xfff00000ull);
+  {
+    int nl_all = 0;
+    for (int c = 0; c < nchains; ++c) nl_all += nlayers[c];
+    for (int l = 0; l < nl_all; ++l) fits32 = fits32 && (!layers[l].out || (size_t)rows * layers[l].ldo * 4 < 0xfff00000ull);
+  }
+  g.fits32 = fits32 ? 1 : 0;
   if (resident_env == 2 && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && (rows & 31) == 0 && fits32 &&
       layers[0].k == 96 && layers[0].n == 64 && layers[1].n == 32 && layers[2].n <= 32 && layers[0].ldw >= 64 && layers[1].ldw >= 32) {
     constexpr size_t lds_wave = sizeof(float) * ((64 + 32) * 32 + 4 * 32 * 97);
