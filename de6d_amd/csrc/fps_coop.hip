@@ -582,6 +582,10 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
           thr[s_] = cv[s_] < 0.f ? 0xFFFFFFFFu : ntk[s_] >= ntk_last ? ubk - 1u : ubk;
         }
         const int jmax = min(max_picks, m - r);
+        // (round 6, as in fps_seq.hip) picks are published after the loop: lane j remembers which lane AND which of its sets
+        // pick j was (the candidate a lane puts forward changes from pick to pick here); coordinates and tie key are constants
+        // of the round, fetched with cross-lane reads once per round
+        int mws = 0;       // lane j: (set << 6) | lane of the candidate pick j was (ONE register: the kernel sits at its 128)
         for (; j < jmax; ++j) {
           // this lane's best (key, ~tie key) over its sets as one 64-bit number
           u64 lbest = 0ull;
@@ -609,11 +613,12 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
           const u64 tie = __ballot(lkey == best);
           int wl = __builtin_ctzll(tie);
           if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~(unsigned)lbest);
-          if (lane == wl) {
-            pick_x[j] = ex; pick_y[j] = ey; pick_z[j] = ez;
-            if (part == 0) idxs[r + j] = sq_tie_key_point(~(unsigned)lbest, log2s) + idx_add;
-          }
           const float sx = d6_readlane_f(ex, wl), sy = d6_readlane_f(ey, wl), sz = d6_readlane_f(ez, wl);
+          {
+            int ls = lset;
+            asm volatile("" : "+v"(ls));       // (a VGPR, whatever form the selects above left the set index in)
+            mws = lane == j ? ((d6_readlane_i(ls, wl) << 6) | wl) : mws;
+          }
           if constexpr (SETS % 2 == 0) {
             const sq_f32x2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
 #pragma unroll
@@ -630,6 +635,22 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
           } else {
 #pragma unroll
             for (int s_ = 0; s_ < SETS; ++s_) cv[s_] = d6_vmin(cv[s_], d6_sqdist(qx[s_] - sx, qy[s_] - sy, qz[s_] - sz));
+          }
+        }
+        {
+          const int src = mws & 63, sset = mws >> 6;
+          float mx = __shfl(qx[0], src), my = __shfl(qy[0], src), mz = __shfl(qz[0], src);
+          unsigned mtk = (unsigned)__shfl((int)ntk[0], src);
+#pragma unroll
+          for (int s_ = 1; s_ < SETS; ++s_) {
+            const float tx = __shfl(qx[s_], src), ty = __shfl(qy[s_], src), tz = __shfl(qz[s_], src);
+            const unsigned tk = (unsigned)__shfl((int)ntk[s_], src);
+            const bool sel = sset == s_;
+            mx = sel ? tx : mx; my = sel ? ty : my; mz = sel ? tz : mz; mtk = sel ? tk : mtk;
+          }
+          if (lane < j) {
+            pick_x[lane] = mx; pick_y[lane] = my; pick_z[lane] = mz;
+            if (part == 0) idxs[r + lane] = sq_tie_key_point(~mtk, log2s) + idx_add;
           }
         }
       }

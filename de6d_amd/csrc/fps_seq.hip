@@ -170,21 +170,34 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
       const unsigned alt = is_last ? ub : 0u;
       int j = 0;
       const int jmax = min(max_picks, m - r);
-      for (; j < jmax; ++j) {
-        const unsigned ekey = (__builtin_bit_cast(unsigned, cv) << 1) + 2u;
-        const unsigned key = ekey >= thr ? ekey : alt;
-        // the largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends
-        const unsigned best = sq_wave_max_u32(key);
-        if (best & 1u) { SQ_STAT(4, 1); break; }
-        const u64 tie = __ballot(key == best);
-        int wl = __builtin_ctzll(tie);
-        if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~ntk);
-        if (lane == wl) {                                  // the holder publishes the pick
-          pick_x[j] = qx; pick_y[j] = qy; pick_z[j] = qz;
-          idxs[r + j] = kidx + idx_add;
+      // (round 6) the picks are PUBLISHED after the loop: lane j remembers WHICH lane's candidate pick j was (one select per
+      // decision) and fetches its coordinates / index with four cross-lane reads once per round, instead of the holder's
+      // exec-masked LDS / global stores with their 64-bit address inside the chain of every decision: 0.440 -> 0.409 us per
+      // pick on the benchmark scenes with the first form of this (values kept per lane)
+      int mwl = 0;       // lane j: the lane whose candidate pick j was (its coordinates and index are constants of the round)
+      if (jmax > 0) {
+        while (true) {
+          const unsigned ekey = (__builtin_bit_cast(unsigned, cv) << 1) + 2u;
+          const unsigned key = ekey >= thr ? ekey : alt;
+          // the largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends
+          const unsigned best = sq_wave_max_u32(key);
+          if (best & 1u) { SQ_STAT(4, 1); break; }
+          const u64 tie = __ballot(key == best);
+          int wl = __builtin_ctzll(tie);
+          if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~ntk);
+          const float sx = d6_readlane_f(qx, wl), sy = d6_readlane_f(qy, wl), sz = d6_readlane_f(qz, wl);
+          mwl = lane == j ? wl : mwl;
+          cv = d6_vmin(cv, d6_sqdist(qx - sx, qy - sy, qz - sz));   // (an empty slot stays at -1)
+          if (++j >= jmax) break;
         }
-        const float sx = d6_readlane_f(qx, wl), sy = d6_readlane_f(qy, wl), sz = d6_readlane_f(qz, wl);
-        cv = d6_vmin(cv, d6_sqdist(qx - sx, qy - sy, qz - sz));   // (an empty slot stays at -1)
+      }
+      {
+        const float mx = __shfl(qx, mwl), my = __shfl(qy, mwl), mz = __shfl(qz, mwl);
+        const int mk = __shfl(kidx, mwl);
+        if (lane < j) {
+          pick_x[lane] = mx; pick_y[lane] = my; pick_z[lane] = mz;
+          idxs[r + lane] = mk + idx_add;
+        }
       }
       if (lane == 0) pick_n = j;
       SQ_STAT(1, j);
