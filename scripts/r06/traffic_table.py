@@ -5,17 +5,12 @@ import os
 
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'profiles')
 GEMM = ('linear_kernel', 'mlp_chain', 'mlp_group', 'mlp_rows')
-out = ["# HBM traffic by kernel family (round 5; `scripts/r06/traffic_table.py` over the eager `rocprofv3 --pmc` passes)", "",
-       "Round-4 review item 8 asked for this table and for one of the three largest writers to go.  What the table says: the",
-       "writers are the LAYER OUTPUTS themselves — `mlp_group` 112 MB per 32-scene pass = the four pooled (centres x C) matrices of",
-       "SA2-B / SA3 / the head's two groups (84 MB algorithmic) plus the integer-max atomics of centres that span several 32-row",
-       "tiles; `mlp_chain` 77 MB = SA1's and SA2-A's pooled rows (84 MB algorithmic, part of the atomics merge in L2); `linear_kernel`",
-       "71 MB = the per-point first-layer sums P and the aggregation outputs.  Every one of them is written once and read once by the",
-       "next launch; none is a re-read or a scratch array (round 2 removed those: expand / chain fusion, contiguous atomics).  Getting",
-       "below them means keeping a level's pooled rows on the chip across launches (one persistent kernel per level), which was not",
-       "attempted: at 14.85 k scenes/s the GEMM family moves 24 MB x 14.85 k = 0.36 TB/s, 4.5 % of the HBM peak — the path is",
-       "matrix-pipe-bound (DESIGN.md §8), not traffic-bound.  This round the engine ball query stopped writing the padded part of its",
-       "index rows (`bq_grid`: SA1 25 -> 4 MB per pass) and `roofline.traffic` became a measurement of the run itself.", ""]
+out = ["# HBM traffic by kernel family (round 6; `scripts/r06/traffic_table.py` over the eager `rocprofv3 --pmc` passes)", "",
+       "Same table as round 5's (`profiles/r05_traffic_by_family.md`), on this round's kernels.  Nothing about the traffic was changed",
+       "in round 6 (review item 7 was 'only after items 1-3'): the writers are still the layer outputs themselves (the pooled rows of",
+       "the group / chain kernels, the per-point first-layer sums and aggregation outputs of `linear_kernel`), each written once and",
+       "read once by the next launch; 23.8 MB per scene in the bench run (`roofline.traffic_bytes_per_scene`) = 0.36 TB/s at 15.2 k",
+       "scenes/s, 4.5 % of the HBM peak.", ""]
 for tag, label in (('z', 'benchmark scenes, eager 32-scene pass'), ('beam', 'ray-cast scenes, eager 32-scene pass'),
                    ('65536', '65536-point scenes, eager 8-scene pass')):
     s = json.load(open(os.path.join(P, 'r06_%s_pmc_summary.json' % tag)))
