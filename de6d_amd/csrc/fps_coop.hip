@@ -586,7 +586,8 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
         // pick j was (the candidate a lane puts forward changes from pick to pick here); coordinates and tie key are constants
         // of the round, fetched with cross-lane reads once per round
         int mws = 0;       // lane j: (set << 6) | lane of the candidate pick j was (ONE register: the kernel sits at its 128)
-        for (; j < jmax; ++j) {
+        bool go;       // ONE loop exit (fps_seq.hip: the decision that ends the round runs the rest of the body harmlessly)
+        do {
           // this lane's best (key, ~tie key) over its sets as one 64-bit number
           u64 lbest = 0ull;
           int lset = 0;
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
           }
           const unsigned lkey = (unsigned)(lbest >> 32);
           const unsigned best = sq_wave_max_u32(lkey);
-          if (best & 1u) break;                              // an unknown region may hold the maximum: the round ends
+          go = (best & 1u) == 0u;                            // odd: an unknown region may hold the maximum: the round ends
           float ex = qx[0], ey = qy[0], ez = qz[0];
 #pragma unroll
           for (int s_ = 1; s_ < SETS; ++s_) {
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(1024) void fps_coop_multi_kernel(int b, int n, int 
 #pragma unroll
             for (int s_ = 0; s_ < SETS; ++s_) cv[s_] = d6_vmin(cv[s_], d6_sqdist(qx[s_] - sx, qy[s_] - sy, qz[s_] - sz));
           }
-        }
+          j += go ? 1 : 0;
+        } while (go && j < jmax);
         {
           const int src = mws & 63, sset = mws >> 6;
           float mx = __shfl(qx[0], src), my = __shfl(qy[0], src), mz = __shfl(qz[0], src);

@@ -175,21 +175,29 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
       // exec-masked LDS / global stores with their 64-bit address inside the chain of every decision: 0.440 -> 0.409 us per
       // pick on the benchmark scenes with the first form of this (values kept per lane)
       int mwl = 0;       // lane j: the lane whose candidate pick j was (its coordinates and index are constants of the round)
-      if (jmax > 0) {
-        while (true) {
+      // ONE loop exit: the decision that ends the round (an odd best key) still runs the rest of the body — its bogus winner
+      // changes cv and lane j's note, which nobody reads again: cv is rebuilt from the records next round and lane j >= the
+      // final j publishes nothing — instead of leaving from the middle: with two exits the backend's structurizer turns both
+      // uniform branches into mask arithmetic (s_cselect / s_and / s_xor / s_andn2: nine scalar instructions per decision)
+      {
+        bool go;
+        do {
           const unsigned ekey = (__builtin_bit_cast(unsigned, cv) << 1) + 2u;
           const unsigned key = ekey >= thr ? ekey : alt;
           // the largest key wins: odd = an unknown region may hold the maximum (ties go to it): the round ends
           const unsigned best = sq_wave_max_u32(key);
-          if (best & 1u) { SQ_STAT(4, 1); break; }
           const u64 tie = __ballot(key == best);
           int wl = __builtin_ctzll(tie);
           if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~ntk);
           const float sx = d6_readlane_f(qx, wl), sy = d6_readlane_f(qy, wl), sz = d6_readlane_f(qz, wl);
           mwl = lane == j ? wl : mwl;
           cv = d6_vmin(cv, d6_sqdist(qx - sx, qy - sy, qz - sz));   // (an empty slot stays at -1)
-          if (++j >= jmax) break;
-        }
+          go = (best & 1u) == 0u;
+          j += go ? 1 : 0;
+#ifdef DET6D_EXPERIMENTS
+          if (!go) SQ_STAT(4, 1);
+#endif
+        } while (go && j < jmax);
       }
       {
         const float mx = __shfl(qx, mwl), my = __shfl(qy, mwl), mz = __shfl(qz, mwl);
