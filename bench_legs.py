@@ -21,9 +21,10 @@ HBM_PEAK_GBS = 8000.0
 
 
 _SAMPLER_CODE = r"""
-import glob, sys, time
+import glob, os, sys, time
 out = open(sys.argv[1], 'w')
 period = float(sys.argv[2])
+parent = os.getppid()
 smi = h = None
 try:                                   # amdsmi: gfx clock of every XCD + socket power (no HIP context is created)
     import amdsmi as smi
@@ -33,7 +34,7 @@ try:                                   # amdsmi: gfx clock of every XCD + socket
 except Exception:
     smi = None
 hw = [d for d in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*') if glob.glob(d + '/freq1_input')]
-while True:
+while os.getppid() == parent:           # (a bench that died mid-stream must not leave its sampler polling for ever)
     t = time.time()
     clk = pw = None
     try:

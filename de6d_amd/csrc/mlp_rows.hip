@@ -688,7 +688,9 @@ DET6D_API int det6d_mlp_rows(int rows, const float *x, int ldx, int xcol0, int n
     for (int l = 0; l < nl_all; ++l) fits32 = fits32 && (!layers[l].out || (size_t)rows * layers[l].ldo * 4 < 0xfff00000ull);
   }
   g.fits32 = fits32 ? 1 : 0;
-  if (resident_env == 2 && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && (rows & 31) == 0 && fits32 &&
+  // (the wave-private kernel forms its scalar byte offsets in signed 32-bit arithmetic: half the range)
+  const bool fits31 = fits32 && (size_t)rows * ldx * 4 < 0x7ff00000ull;
+  if (resident_env == 2 && nchains == 1 && nlayers[0] == 3 && g.kchunk == g.k0 && g.vec4 && rows >= 16384 && (rows & 31) == 0 && fits31 &&
       layers[0].k == 96 && layers[0].n == 64 && layers[1].n == 32 && layers[2].n <= 32 && layers[0].ldw >= 64 && layers[1].ldw >= 32) {
     constexpr size_t lds_wave = sizeof(float) * ((64 + 32) * 32 + 4 * 32 * 97);
     DET6D_MAX_DYNAMIC_LDS((mlp_rows_wave_kernel<96, 64, 32>), lds_wave);
