@@ -571,6 +571,9 @@ __global__ __launch_bounds__(512) void fps_standin_kernel(int n, int m, int *idx
 // fps_coop.hip: register-resident D-FPS of 32768 / 65536-point scenes by cooperating workgroups
 bool det6d_fps_coop_handles(int n);
 long long det6d_fps_coop_workspace_bytes(int b, int n);
+int det6d_fps_cells_w_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                             const float *xyz, int *perm, int *idx, const float *weights, long long w_bstride, float gamma,
+                             int w_is_score, hipStream_t stream);      // fps_cells.hip
 bool det6d_fps_coop_fits_device(int n);      // fps_coop.hip: the current device holds one cooperative launch (>= 8 x parts CUs)
 int det6d_fps_coop_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
                           const float *xyz, void *workspace, int *idx, hipStream_t stream);
@@ -619,6 +622,20 @@ DET6D_API int det6d_fps_fused(int b, int n_total, int lo, int hi, int m, const f
   vw.gamma = gamma;
   const float *x = xyz ? xyz + (size_t)lo * 3 : nullptr;
   int *out = idx ? idx + idx_offset : nullptr;
+  // (round 6) S-FPS of 16384- / 4096-point clouds in the multi-pick form (fps_seq.hip: fps_seq_w_kernel on the k-d regions of
+  // fps_cells.hip), behind it the guarded exact-double launch for scenes that hold a weight below 1e-12; DET6D_FPS_SEQW=0
+  // (knobs / experiments build): the one-pick fat-thread kernel of rounds 2-5
+  static const int seqw = det6d_env_int("DET6D_FPS_SEQW", 1);
+  if (scores && seqw && temp && x && out && b > 0 && m > 0 && m <= n && (n == 16384 || n == 4096) && !no_fastw()) {
+    const int log2s = opt_n_threads_log2(n);
+    const int rc = det6d_fps_cells_w_launch(b, n, m, log2s, vw.xyz_bstride, vw.idx_bstride, lo + idx_bias, x, reinterpret_cast<int *>(temp),
+                                            out, scores + lo, vw.w_bstride, gamma, 1, (hipStream_t)stream);
+    if (rc != DET6D_OK) return rc;
+    const int S = 1 << log2s;
+    hipLaunchKernelGGL((fps_mem_kernel<true>), dim3(b), dim3(S < 64 ? 64 : S), 0, (hipStream_t)stream, n, m, log2s, x, scores + lo, temp, out,
+                       vw, 1);
+    return det6d_check_launch("det6d_fps (score-weighted, guarded exact launch)");
+  }
   if (scores) return launch_fps<true>(b, n, m, x, scores + lo, temp, out, vw, (hipStream_t)stream);
 #ifdef DET6D_EXPERIMENTS
   static const int standin = det6d_env_int("DET6D_FPS_STANDIN", 0);

@@ -396,3 +396,18 @@ int det6d_fps_cells_launch(int b, int n, int m, int log2s, long long xyz_bstride
 #endif
   return det6d_fps_seq_launch(b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, stream);
 }
+
+// the score-weighted form: k-d pre-pass (a permutation of the scene: the weights play no part in it) + fps_seq_w_kernel
+int det6d_fps_seq_w_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                           const float *xyz, const int *perm, int *idx, const float *weights, long long w_bstride, float gamma,
+                           int w_is_score, int *flags, hipStream_t stream);      // fps_seq.hip
+int det6d_fps_cells_w_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                             const float *xyz, int *perm, int *idx, const float *weights, long long w_bstride, float gamma,
+                             int w_is_score, hipStream_t stream) {
+  if (n != 16384 && n != 4096) return DET6D_EINVAL;
+  if (n == 4096) hipLaunchKernelGGL((cell_sort_kernel<4>), dim3(b), dim3(1024), 0, stream, n, log2s, xyz_bstride, xyz, perm);
+  else hipLaunchKernelGGL((cell_sort_kernel<16>), dim3(b), dim3(1024), 0, stream, n, log2s, xyz_bstride, xyz, perm);
+  return det6d_fps_seq_w_launch(b, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, weights, w_bstride, gamma, w_is_score,
+                                perm, stream);
+}
+

@@ -59,6 +59,20 @@ __device__ __forceinline__ void sq_select(int ws, const float (&px)[N], const fl
   }
 }
 
+// the same search over five register arrays (score-weighted sampler: coordinates, min-distance and weight of a slot)
+template <int LO, int HI, int N>
+__device__ __forceinline__ void sq_select5(int ws, const float (&px)[N], const float (&py)[N], const float (&pz)[N],
+                                           const float (&pt)[N], const float (&pw)[N], float &x, float &y, float &z, float &t, float &w) {
+  if constexpr (HI - LO == 1) {
+    x = px[LO]; y = py[LO]; z = pz[LO]; t = pt[LO]; w = pw[LO];
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(t), "+v"(w));
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (ws < MID) sq_select5<LO, MID>(ws, px, py, pz, pt, pw, x, y, z, t, w);
+    else sq_select5<MID, HI>(ws, px, py, pz, pt, pw, x, y, z, t, w);
+  }
+}
+
 // max over the four lanes of every quad (lanes 4q .. 4q+3), in all four lanes; two values at once (the DPP steps interleave)
 __device__ __forceinline__ void sq_quad_max2(float a, float b, float &ra, float &rb) {
   asm volatile(
@@ -225,6 +239,12 @@ struct SqRecords {
   int nc[kWaves];
 };
 
+// score-weighted sampler (round 6): min-distance and weight of every candidate beside its score (SqRecords::v), so that the
+// sequencer can keep the SCORE of a candidate exact (score = fp32(t * w): fps.hip, S-FPS in exact fp32)
+struct SqRecordsW {
+  float t[64], w[64];
+};
+
 // Exact duplicates inside a lane.  A lane's slots are in the reference's order, so a point P' with the coordinates of an
 // earlier slot P of the same lane has P's min-distance at all times and loses every tie against it: P' is never the arg-max
 // of anything.  Its min-distance starts at 0 instead of 1e10, which takes it out of the lane's best / second bookkeeping —
@@ -239,6 +259,19 @@ __device__ __forceinline__ void sq_hide_lane_duplicates(const float (&px)[SG], c
     bool dup = false;
 #pragma unroll
     for (int i = 0; i < j; ++i) dup |= px[i] == px[j] && py[i] == py[j] && pz[i] == pz[j];
+    pt[j] = dup ? 0.f : pt[j];
+  }
+}
+
+// score-weighted form: a duplicate must carry the same weight too (equal coordinates with another weight is another score)
+template <int SG>
+__device__ __forceinline__ void sq_hide_lane_duplicates_w(const float (&px)[SG], const float (&py)[SG], const float (&pz)[SG],
+                                                          const float (&pw)[SG], float (&pt)[SG]) {
+#pragma unroll
+  for (int j = 1; j < SG; ++j) {
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < j; ++i) dup |= px[i] == px[j] && py[i] == py[j] && pz[i] == pz[j] && pw[i] == pw[j];
     pt[j] = dup ? 0.f : pt[j];
   }
 }
@@ -351,6 +384,91 @@ __device__ __forceinline__ float sq_rescan(float cx, float cy, float cz, int log
   }
   if (lane == 0) rec.nc[wave] = nc;
   return cmax;
+}
+
+// sq_rescan of the SCORE-WEIGHTED sampler (S-FPS: arg-max of fp32(min-distance x weight), sampling_gpu.cu:419-540): the same
+// scan and extraction on the scores; min-distances stay what the picks are applied to.  The record carries score, index,
+// coordinates (SqRecords) and min-distance + weight (SqRecordsW).  Returns the region's maximal MIN-DISTANCE — what the
+// owners' box test needs: a pick at least sqrt(that) away from the box lowers no min-distance of the region, hence no score.
+template <int SG, int kCand>
+__device__ __forceinline__ float sq_rescan_w(float cx, float cy, float cz, int log2s, const float (&px)[SG], const float (&py)[SG],
+                                             const float (&pz)[SG], const float (&pw)[SG], float (&pt)[SG],
+                                             const unsigned short *korig_w, SqRecords &rec, SqRecordsW &recw, int wave,
+                                             int depth = kCand) {
+  const int lane = threadIdx.x & 63;
+  float best = -1.0f, sec = -1.0f, tm = 0.f;
+  int bs = 0;
+  const sq_f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+  auto visit = [&](int j, float d) {
+    const float t = d6_vmin(d, pt[j]);
+    pt[j] = t;
+    tm = d6_vmax(tm, t);
+    const float sc = t * pw[j];
+    sec = __builtin_amdgcn_fmed3f(best, sec, sc);         // second best so far (uses the OLD best)
+    const bool up = sc > best;
+    bs = up ? j : bs;
+    best = d6_vmax(best, sc);
+  };
+#pragma unroll
+  for (int q = 0; q < SG / 2; ++q) {
+    const int s0 = 2 * q;
+    const sq_f32x2 dx = sq_f32x2{px[s0], px[s0 + 1]} - c2x;
+    const sq_f32x2 dy = sq_f32x2{py[s0], py[s0 + 1]} - c2y;
+    const sq_f32x2 dz = sq_f32x2{pz[s0], pz[s0 + 1]} - c2z;
+    sq_f32x2 d = dy * dy;
+    d = __builtin_elementwise_fma(dx, dx, d);
+    d = __builtin_elementwise_fma(dz, dz, d);
+    visit(s0, d[0]);
+    visit(s0 + 1, d[1]);
+  }
+  auto second_slot = [&]() -> int {                      // lowest slot != bs holding the lane's second SCORE
+    float target = sec;
+    int skip = bs;
+    asm volatile("" : "+v"(target), "+v"(skip));
+    int ss = 0;
+#pragma unroll
+    for (int j = SG - 1; j >= 0; --j) ss = (pt[j] * pw[j] == target && j != skip) ? j : ss;
+    return ss;
+  };
+  int taken = 0;
+  float head = best;
+  int nc = 0;
+#pragma nounroll
+  for (int i = 0; i < depth; ++i) {
+    const float wm = d6_wave_max(head);
+    const u64 tie = __ballot(head == wm);
+    int wl = __builtin_ctzll(tie);
+    int ss = 0;
+    bool have_ss = false;
+    if (__popcll(tie) != 1) {                              // equal heads: the reference's key decides
+      if (__ballot(taken != 0 && head == wm) != 0ull) { ss = second_slot(); have_ss = true; }
+      const int hs = taken ? ss : bs;
+      wl = sq_min_key_lane(tie, sq_tie_key((int)korig_w[lane * SG + hs], log2s));
+    }
+    const int wtk = d6_readlane_i(taken, wl);
+    int ws;
+    if (wtk == 0) {
+      ws = d6_readlane_i(bs, wl);
+    } else {
+      if (!have_ss) ss = second_slot();
+      ws = d6_readlane_i(ss, wl);
+    }
+    if (lane == wl) {                                      // the holder writes its candidate
+      float x, y, z, t, w;
+      sq_select5<0, SG>(ws, px, py, pz, pt, pw, x, y, z, t, w);
+      const int o = wave * kCandMax + i;
+      rec.v[o] = wm;
+      rec.k[o] = (int)korig_w[lane * SG + ws];
+      rec.x[o] = x; rec.y[o] = y; rec.z[o] = z;
+      recw.t[o] = t; recw.w[o] = w;
+      taken = 1;
+      head = sec;
+    }
+    nc = i + 1;
+    if (wtk != 0) break;                                   // a lane is exhausted: the list ends here
+  }
+  if (lane == 0) rec.nc[wave] = nc;
+  return d6_wave_max(tm);
 }
 
 }  // namespace

@@ -225,6 +225,192 @@ __global__ __launch_bounds__(1024) void fps_seq_kernel(int n, int m, int log2s, 
 #endif
 }
 
+// ---- round 6: the SCORE-WEIGHTED sampler (S-FPS) in the multi-pick form ------------------------------------------------------
+// furthest_point_sampling_weights_kernel (sampling_gpu.cu:419-540): pick 0 = arg-max of the weights, pick j > 0 = arg-max of
+// float(double(min-distance) * max(double(w), 1e-12)), the reference's tie order.  While every weight of the scene is >= 1e-12
+// (and none is NaN) that score is the IEEE fp32 product t * w (fps.hip, "S-FPS in exact fp32"); a scene that holds a smaller
+// weight flags itself in the first word of its scratch and leaves: the guarded memory-resident launch behind this one samples
+// it with the double expression (same protocol as fps_fat_kernel<.., FASTW>).
+// Same rounds as fps_seq_kernel: records hold a region's top candidates BY SCORE (+ their min-distance and weight), the
+// sequencer keeps every candidate's min-distance exact and rebuilds its score per decision (one more multiply in the chain),
+// a region whose best candidate has sunk below the record's last one is unknown with that candidate's old SCORE as the bound
+// (scores only decrease: the weights are constants), and the owners' box test compares a pick's distance to the box with the
+// region's maximal MIN-DISTANCE (a pick that far away lowers no min-distance, hence no score).
+template <int kCand, int SG>
+__global__ __launch_bounds__(1024) void fps_seq_w_kernel(int n, int m, int log2s, long long xyz_bstride, long long idx_bstride,
+                                                         int idx_add, const float *__restrict__ xyz, const int *__restrict__ perm,
+                                                         int *__restrict__ idxs, int max_picks, int depth_add,
+                                                         const float *__restrict__ weights, long long w_bstride, float gamma,
+                                                         int w_is_score, int *__restrict__ flags) {
+  __shared__ unsigned short korig[64 * kWaves * SG];       // sorted position -> original index
+  __shared__ SqRecords rec;
+  __shared__ SqRecordsW recw;
+  __shared__ float pick_x[kMaxPicks], pick_y[kMaxPicks], pick_z[kMaxPicks];
+  __shared__ int pick_n;
+  __shared__ float w0_val[kWaves], w0_x[kWaves], w0_y[kWaves], w0_z[kWaves];
+  __shared__ unsigned w0_key[kWaves];
+  __shared__ int small_any;
+  const int h = threadIdx.x, lane = h & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(h >> 6);
+  xyz += (size_t)blockIdx.x * xyz_bstride;
+  perm += (size_t)blockIdx.x * n;
+  idxs += (size_t)blockIdx.x * idx_bstride;
+  weights += (size_t)blockIdx.x * w_bstride;
+  flags += (size_t)blockIdx.x * n;                         // the scene's scratch (= its permutation: read below, then free)
+  unsigned short *korig_w = korig + (size_t)wave * 64 * SG;
+  if (h == 0) small_any = 0;
+
+  float px[SG], py[SG], pz[SG], pt[SG], pw[SG];
+  float lox, loy, loz, hix, hiy, hiz;
+  bool small = false;
+  {
+    float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+      const int pos = (wave * 64 + lane) * SG + j;
+      const int k = perm[pos];
+      korig[pos] = (unsigned short)k;
+      px[j] = xyz[(size_t)k * 3 + 0];
+      py[j] = xyz[(size_t)k * 3 + 1];
+      pz[j] = xyz[(size_t)k * 3 + 2];
+      float w = weights[k];
+      if (w_is_score) w = d6_sigmoid_powf(w, gamma);
+      pw[j] = w;
+      small = small || !((double)w >= 1e-12);
+      asm volatile("" : "+v"(px[j]), "+v"(py[j]), "+v"(pz[j]), "+v"(pw[j]));
+      pt[j] = 1e10f;
+      ax = d6_vmin(ax, px[j]); bx = d6_vmax(bx, px[j]);
+      ay = d6_vmin(ay, py[j]); by = d6_vmax(by, py[j]);
+      az = d6_vmin(az, pz[j]); bz = d6_vmax(bz, pz[j]);
+    }
+    lox = d6_wave_min(ax); hix = d6_wave_max(bx);
+    loy = d6_wave_min(ay); hiy = d6_wave_max(by);
+    loz = d6_wave_min(az); hiz = d6_wave_max(bz);
+  }
+  __syncthreads();                                         // small_any initialised; every thread has read its part of the permutation
+  if (__ballot(small) != 0ull && lane == 0) small_any = 1;
+  // ---- pick 0: arg-max of the weights (sampling_gpu.cu:452-455), ties by the reference's key.  A lane's slots are in key
+  // order, so its first maximum is its smallest key.
+  {
+    float bw = pw[0];
+    int bs0 = 0;
+#pragma unroll
+    for (int j = 1; j < SG; ++j) {
+      const bool up = pw[j] > bw;
+      bs0 = up ? j : bs0;
+      bw = up ? pw[j] : bw;
+    }
+    const float wm = d6_wave_max(small ? 0.f : bw);        // (a flagged scene leaves below: whatever this computes is dropped)
+    const u64 tie = __ballot(bw == wm);
+    int wl = tie ? __builtin_ctzll(tie) : 0;
+    const unsigned mykey = sq_tie_key((int)korig_w[lane * SG + bs0], log2s);
+    if (__popcll(tie) > 1) wl = sq_min_key_lane(tie, mykey);
+    if (lane == wl) {
+      float x, y, z;
+      sq_select<0, SG>(bs0, px, py, pz, x, y, z);
+      w0_val[wave] = bw; w0_key[wave] = mykey; w0_x[wave] = x; w0_y[wave] = y; w0_z[wave] = z;
+    }
+  }
+  __syncthreads();
+  if (h == 0) flags[0] = small_any;                        // (the permutation has been consumed: first barrier above)
+  if (small_any) return;                                   // sampled by the guarded exact-double launch behind this one
+  if (wave == 0) {
+    const bool mine = lane < kWaves;
+    const float v = mine ? w0_val[lane & (kWaves - 1)] : -1.0f;
+    const unsigned key = mine ? w0_key[lane & (kWaves - 1)] : 0xFFFFFFFFu;
+    const float vm = d6_wave_max(v);
+    const u64 tie = __ballot(mine && v == vm);
+    int wl = __builtin_ctzll(tie);
+    if (__popcll(tie) > 1) wl = sq_min_key_lane(tie, key);
+    if (lane == wl) {
+      pick_x[0] = w0_x[lane]; pick_y[0] = w0_y[lane]; pick_z[0] = w0_z[lane];
+      pick_n = 1;
+      idxs[0] = sq_tie_key_point(key, log2s) + idx_add;
+    }
+  }
+  sq_hide_lane_duplicates_w<SG>(px, py, pz, pw, pt);
+  float cmax = __builtin_inff();
+  __syncthreads();
+
+  int r = 1;                                              // picks made so far
+  while (true) {
+    // ---- A. every wave: the picks of the last round against its points
+    {
+      const int np = pick_n;
+      const float sx = pick_x[lane & (kMaxPicks - 1)], sy = pick_y[lane & (kMaxPicks - 1)], sz = pick_z[lane & (kMaxPicks - 1)];
+      const float gx = fmaxf(0.f, fmaxf(lox - sx, sx - hix));
+      const float gy = fmaxf(0.f, fmaxf(loy - sy, sy - hiy));
+      const float gz = fmaxf(0.f, fmaxf(loz - sz, sz - hiz));
+      const float lb = d6_sqdist(gx, gy, gz);
+      u64 need = __ballot(lane < np && (r == 1 || !(lb >= cmax)));
+      if (need != 0ull) {
+        while (need & (need - 1ull)) {
+          const int i = __builtin_ctzll(need);
+          need &= need - 1ull;
+          sq_apply<SG>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), px, py, pz, pt);
+        }
+        const int i = __builtin_ctzll(need);
+        cmax = sq_rescan_w<SG, kCand>(d6_readlane_f(sx, i), d6_readlane_f(sy, i), d6_readlane_f(sz, i), log2s, px, py, pz, pw, pt, korig_w,
+                                      rec, recw, wave, np <= depth_add ? min(kCand, 2) : kCand);
+      }
+    }
+    if (r >= m) break;
+    __syncthreads();                                      // records complete
+    // ---- B. wave 0: as many picks as the records allow
+    if (wave == 0) {
+      constexpr int LOG2K = kCand == 2 ? 1 : 2;
+      const bool live = lane < kWaves * kCand;
+      const int region = live ? lane >> LOG2K : 0;
+      const int nc = rec.nc[region];
+      const int slot = lane & (kCand - 1);
+      const int o = region * kCandMax + slot;
+      const bool alive = live && slot < nc;
+      float cv = alive ? recw.t[o] : -1.0f;               // current MIN-DISTANCE of this candidate (-1: no candidate in this slot)
+      const float cw = alive ? recw.w[o] : 1.0f;          // its weight: score = cv * cw (an empty slot stays at -1)
+      const float sv = alive ? rec.v[o] : -1.0f;          // its score as the record was written
+      const float qx = rec.x[o], qy = rec.y[o], qz = rec.z[o];
+      const int kidx = rec.k[o];
+      const bool is_last = live && slot == nc - 1;
+      const float bound_v = sq_group_max<kCand>(is_last ? sv : -2.0f);   // SCORE of the record's last candidate (group-uniform)
+      const unsigned ub = ((__builtin_bit_cast(unsigned, bound_v) << 1) | 1u) + 2u;
+      const unsigned ntk = ~sq_tie_key(kidx, log2s);                                  // larger = earlier in the order
+      const unsigned ntk_last = sq_group_max_u32<kCand>(is_last ? ntk : 0u);
+      const unsigned thr = !alive ? 0xFFFFFFFFu : ntk >= ntk_last ? ub - 1u : ub;
+      const unsigned alt = is_last ? ub : 0u;
+      int j = 0;
+      const int jmax = min(max_picks, m - r);
+      int mwl = 0;
+      {
+        bool go;
+        do {
+          const unsigned ekey = (__builtin_bit_cast(unsigned, cv * cw) << 1) + 2u;
+          const unsigned key = ekey >= thr ? ekey : alt;
+          const unsigned best = sq_wave_max_u32(key);
+          const u64 tie = __ballot(key == best);
+          int wl = __builtin_ctzll(tie);
+          if (__popcll(tie) != 1) wl = sq_min_key_lane(tie, ~ntk);
+          const float sx = d6_readlane_f(qx, wl), sy = d6_readlane_f(qy, wl), sz = d6_readlane_f(qz, wl);
+          mwl = lane == j ? wl : mwl;
+          cv = d6_vmin(cv, d6_sqdist(qx - sx, qy - sy, qz - sz));
+          go = (best & 1u) == 0u;
+          j += go ? 1 : 0;
+        } while (go && j < jmax);
+      }
+      {
+        const float mx = __shfl(qx, mwl), my = __shfl(qy, mwl), mz = __shfl(qz, mwl);
+        const int mk = __shfl(kidx, mwl);
+        if (lane < j) {
+          pick_x[lane] = mx; pick_y[lane] = my; pick_z[lane] = mz;
+          idxs[r + lane] = mk + idx_add;
+        }
+      }
+      if (lane == 0) pick_n = j;
+    }
+    __syncthreads();                                      // picks published
+    r += pick_n;
+  }
+}
+
 }  // namespace
 
 #ifdef DET6D_EXPERIMENTS
@@ -325,4 +511,25 @@ int det6d_fps_seq_launch(int b, int n, int m, int log2s, long long xyz_bstride, 
   else
     hipLaunchKernelGGL((fps_seq_kernel<4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm, idx, max_picks, depth_add);
   return det6d_check_launch("det6d_fps (multi-pick)");
+}
+
+// The score-weighted form (S-FPS of 16384- / 4096-point clouds): `flags` = the scenes' scratch (b x n ints: the permutation the
+// pre-pass wrote; word 0 of a scene becomes its "needs the exact-double sampler" flag), weights / raw scores (b x w_bstride).
+int det6d_fps_seq_w_launch(int b, int n, int m, int log2s, long long xyz_bstride, long long idx_bstride, int idx_add,
+                           const float *xyz, const int *perm, int *idx, const float *weights, long long w_bstride, float gamma,
+                           int w_is_score, int *flags, hipStream_t stream) {
+  if (n != 16384 && n != 4096) return DET6D_EINVAL;
+  static const int max_picks_env = det6d_env_int("DET6D_FPS_SEQ_PICKS", kMaxPicks);
+  static const int depth_add = det6d_env_int("DET6D_FPS_SEQ_DEPTH_ADD", 1);
+  const int max_picks = max_picks_env < 1 ? 1 : max_picks_env > kMaxPicks ? kMaxPicks : max_picks_env;
+#ifdef DET6D_EXPERIMENTS
+  det6d_dbg_poison_lds_hook(stream);
+#endif
+  if (n == 4096)
+    hipLaunchKernelGGL((fps_seq_w_kernel<4, 4>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm,
+                       idx, max_picks, depth_add, weights, w_bstride, gamma, w_is_score, flags);
+  else
+    hipLaunchKernelGGL((fps_seq_w_kernel<4, 16>), dim3(b), dim3(1024), 0, stream, n, m, log2s, xyz_bstride, idx_bstride, idx_add, xyz, perm,
+                       idx, max_picks, depth_add, weights, w_bstride, gamma, w_is_score, flags);
+  return det6d_check_launch("det6d_fps (multi-pick, score-weighted)");
 }
