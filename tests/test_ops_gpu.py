@@ -325,12 +325,15 @@ def test_ball_query_pair_matches_two_queries(ext, oracle_ops, n, m, sa, sb):
         np.testing.assert_array_equal(ib.cpu().numpy(), oib)
 
 
-@pytest.mark.parametrize("n,m", [(4096, 512), (512, 256), (16384, 700), (2048, 300)])
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 256), (16384, 700), (2048, 300), (16384, 2048), (4096, 4096)])
 def test_weighted_sampler_fp32_scoring_and_its_exact_double_fallback(ext, oracle_ops, n, m):
     """S-FPS through det6d_fps_fused (round 5): scenes whose weights are all >= 1e-12 are scored with one fp32 multiply per
     point (exactly float(double(t) * double(w)): the product of two floats is exact in double); a scene holding a weight below
     1e-12 (sigmoid(score) ** gamma underflowing it) or a NaN weight hands itself over to the exact-double launch behind.
-    Scenes of both kinds in ONE call, against the oracle's restatement of sampling_gpu.cu:419-540."""
+    Scenes of both kinds in ONE call, against the oracle's restatement of sampling_gpu.cu:419-540.  From round 6 the 16384- and
+    4096-point clouds go through the MULTI-PICK score-weighted kernel (fps_seq.hip: fps_seq_w_kernel; (16384, 2048) is the second
+    layer of the 65536-point configuration, (4096, 4096) samples every point): records by score, the region bound on scores, the
+    box test on min-distances, pick 0 = arg-max of the weights in the reference's tie order, scene 4 = ties everywhere."""
     fused = ext[2]
     b = 5
     pts = make_batch(170 + n, b, n, dup_frac=0.1)
