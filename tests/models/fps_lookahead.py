@@ -21,6 +21,12 @@ Agents
       the region was ordered after that candidate when the record was made and min-distances only decrease), else unknown
       with that candidate's old value as bound.
     pick r = best exact X, provided every unknown region's bound is strictly below its value; else wait for records.
+
+Round 6: `weights` — the score-weighted sampler (de6d_amd/csrc/fps_seq.hip: fps_seq_w_kernel; furthest_point_sampling_weights_kernel,
+sampling_gpu.cu:419-540 with every weight >= 1e-12).  Values become SCORES (fp32(min-distance x weight)) in records, bounds and
+comparisons; the owners still hold and update MIN-DISTANCES, their skip test still compares the pick's distance to the box with
+the region's maximal min-distance, the sequencer tracks its candidates' min-distances and rebuilds their scores; the first pick
+is the arg-max of the weights under the reference's order.
 """
 import numpy as np
 
@@ -43,24 +49,38 @@ def opt_log2s(n):
     return int(np.log2(min(max(s, 1), 1024)))
 
 
-def fps_sequential(xyz, m):
+def first_pick(n, log2s, weights):
+    """point 0 (D-FPS, sampling_gpu.cu:131-133) or the arg-max of the weights under the reference's order (S-FPS, :452-455)"""
+    if weights is None:
+        return 0
+    w = np.asarray(weights, np.float32)
+    cand = np.nonzero(w == w.max())[0]
+    return int(min(cand, key=lambda k: tie_key(k, log2s)))
+
+
+def fps_sequential(xyz, m, weights=None):
+    """plain sequential restatement; weights: the score-weighted sampler (arg-max of fp32(min-distance x weight), weights >=
+    1e-12: furthest_point_sampling_weights_kernel, sampling_gpu.cu:419-540)"""
     n = xyz.shape[0]
     log2s = opt_log2s(n)
     keys = np.array([tie_key(k, log2s) for k in range(n)], dtype=object)
     t = np.full(n, 1e10, np.float32)
-    picks = [0]
+    w = None if weights is None else np.asarray(weights, np.float32)
+    picks = [first_pick(n, log2s, weights)]
     for _ in range(1, m):
         t = np.minimum(t, sqdist(xyz, xyz[picks[-1]]))
-        v = t.max()
-        cand = np.nonzero(t == v)[0]
+        sc = t if w is None else (t * w).astype(np.float32)
+        v = sc.max()
+        cand = np.nonzero(sc == v)[0]
         picks.append(int(min(cand, key=lambda k: keys[k])))
     return picks
 
 
 class Region:
-    def __init__(self, ids, xyz, log2s, hide=None):
+    def __init__(self, ids, xyz, log2s, hide=None, weights=None):
         self.ids = np.asarray(ids)
         self.p = xyz[self.ids]
+        self.w = np.ones(len(ids), np.float32) if weights is None else np.asarray(weights, np.float32)[self.ids]
         self.t = np.full(len(ids), 1e10, np.float32)
         self.keys = [tie_key(k, log2s) for k in self.ids]
         # sq_hide_lane_duplicates (csrc/fps_multi.h): a point with the coordinates of a point of the same region that comes
@@ -69,7 +89,7 @@ class Region:
         if hide is not None:
             seen = {}
             for i in sorted(range(len(self.ids)), key=lambda i: self.keys[i]):
-                c = tuple(self.p[i].tolist())
+                c = tuple(self.p[i].tolist()) + (float(self.w[i]),)      # (weighted form: a duplicate carries the same weight too)
                 if c in seen and hide.random() < 0.7:
                     self.t[i] = np.float32(0)
                 seen.setdefault(c, i)
@@ -82,11 +102,15 @@ class Region:
         return sqdist(g[None], np.zeros(3, np.float32))[0]
 
     def top2(self, k=2):
-        order = sorted(range(len(self.ids)), key=lambda i: (-float(self.t[i]), self.keys[i]))[:k]
-        return [(np.float32(self.t[i]), int(self.ids[i]), self.p[i].copy()) for i in order]
+        """the record: top candidates by SCORE (= min-distance x weight; weight 1 for D-FPS) as (score, index, position,
+        min-distance, weight)"""
+        sc = (self.t * self.w).astype(np.float32)
+        order = sorted(range(len(self.ids)), key=lambda i: (-float(sc[i]), self.keys[i]))[:k]
+        return [(np.float32(sc[i]), int(self.ids[i]), self.p[i].copy(), np.float32(self.t[i]), np.float32(self.w[i])) for i in order]
 
 
-def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2, hide_duplicates=False, kernel_keys=False):
+def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=None, depth=2, hide_duplicates=False, kernel_keys=False,
+        weights=None):
     """regions: list of index arrays partitioning range(n).  Returns the picks; raises on a protocol violation.
     greedy: the sequencer decides until it is blocked, then every owner catches up (counts how often a rescan is on the
     critical path: stats['blocks'])."""
@@ -96,9 +120,15 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
     log2s = opt_log2s(n)
     key = lambda k: tie_key(k, log2s)
     better = lambda a, b: a[0] > b[0] or (a[0] == b[0] and key(a[1]) <= key(b[1]))      # a >= b in the order
-    owners = [Region(ids, xyz, log2s, hide=np.random.default_rng(seed + 77) if hide_duplicates else None) for ids in regions]
-    hist = [xyz[0].copy()]          # published picks (positions); hist[0] is point 0
-    picks = [0]
+    owners = [Region(ids, xyz, log2s, hide=np.random.default_rng(seed + 77) if hide_duplicates else None, weights=weights)
+              for ids in regions]
+    # weights (round 6, fps_seq.hip: fps_seq_w_kernel): records rank by SCORE, the sequencer keeps the candidates' MIN-DISTANCES
+    # exact and rebuilds the scores, the unknown-region bound is the last candidate's old score, the owners' skip test compares
+    # the pick's distance to the box with the region's maximal MIN-DISTANCE
+    score = lambda cv, c: np.float32(np.float32(cv) * c[4])
+    p0 = first_pick(n, log2s, weights)
+    hist = [xyz[p0].copy()]         # published picks (positions); hist[0] is point 0 (D-FPS) / the arg-max of the weights
+    picks = [p0]
     records = [None] * len(owners)  # published: (tag, [(v1,k1,p1), (v2,k2,p2)])
     seq = [dict(tag=0, rec=None, cv=None) for _ in owners]
     blocked_polls = decisions = 0
@@ -124,7 +154,7 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
             if r is not None and r[0] > st['tag']:
                 assert r[0] <= len(hist)
                 st['tag'], st['rec'] = r[0], r[1]
-                cv = [c[0] for c in r[1]]
+                cv = [c[3] for c in r[1]]                        # min-distances (== the values for D-FPS)
                 for i in range(r[0], len(hist)):                 # picks made since the record
                     for j in range(len(cv)):
                         cv[j] = min(cv[j], sqdist(r[1][j][2][None], hist[i])[0])
@@ -142,10 +172,10 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
             v_l, k_l = st['rec'][-1][0], st['rec'][-1][1]
             ub = 2 * bits(v_l) + 3
             for j, (cv, c) in enumerate(zip(st['cv'], st['rec'])):
-                ekey = 2 * bits(cv) + 2
+                ekey = 2 * bits(score(cv, c)) + 2
                 thr = ub - 1 if key(c[1]) <= key(k_l) else ub
                 if ekey >= thr:
-                    entries.append((ekey, key(c[1]), (cv, c[1], c[2])))
+                    entries.append((ekey, key(c[1]), (score(cv, c), c[1], c[2])))
                 elif j == len(st['rec']) - 1:
                     entries.append((ub, None, None))
         top = max(e[0] for e in entries)
@@ -166,7 +196,7 @@ def run(xyz, m, regions, seed=0, max_batch=3, stats=None, greedy=False, delay=No
         for st in seq:
             if st['rec'] is None:
                 return False
-            cands = [(cv, c[1], c[2]) for cv, c in zip(st['cv'], st['rec'])]
+            cands = [(score(cv, c), c[1], c[2]) for cv, c in zip(st['cv'], st['rec'])]
             x = cands[0]
             for c in cands[1:]:
                 if not better(x, c):

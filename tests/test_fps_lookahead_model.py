@@ -149,3 +149,35 @@ def test_lists_of_varying_length(case):
         assert M.run(xyz, m, regs, greedy=True, depth=0, kernel_keys=True, hide_duplicates=True, stats={}, seed=seed) == want
         assert M.run(xyz, m, regs, delay=2, depth=0, kernel_keys=True, seed=seed) == want
         assert M.run(xyz, m, regs, depth=0, seed=seed) == want
+
+
+@pytest.mark.parametrize("case", ["uniform", "lattice_equal_weights", "duplicates", "few_weight_levels"])
+@pytest.mark.parametrize("kernel_keys", [False, True])
+def test_score_weighted_rule_equals_sequential_weighted_fps(case, kernel_keys):
+    """round 6, csrc/fps_seq.hip: fps_seq_w_kernel — the same rounds on SCORES (min-distance x weight): records ranked by score
+    with min-distance and weight beside it, the sequencer's candidates tracked by min-distance, the unknown bound = the last
+    candidate's old score, the owners' skip test on the region's maximal MIN-DISTANCE, pick 0 = arg-max of the weights under the
+    reference's order.  Random, lockstep and delayed schedules, hidden duplicates, the kernels' key scheme."""
+    rng = np.random.default_rng(11)
+    n, m, nreg = 512, 128, 16
+    if case == "uniform":
+        xyz = rng.uniform(-10, 10, (n, 3))
+        w = 1.0 / (1.0 + np.exp(-rng.normal(size=n) * 2))
+    elif case == "lattice_equal_weights":          # exact score ties everywhere, pick 0 decided by the order alone
+        xyz = rng.integers(0, 6, (n, 3)).astype(np.float64)
+        w = np.full(n, 0.75)
+    elif case == "duplicates":                     # repeated points, some with the same weight, some with another
+        base = rng.uniform(-10, 10, (n // 4, 3))
+        src = rng.integers(0, n // 4, n)
+        xyz = base[src]
+        w = np.where(rng.random(n) < 0.5, 0.5, 1.0 / (1.0 + np.exp(-rng.normal(size=n))))
+    else:                                          # a handful of weight levels: ties between points of different regions
+        xyz = rng.uniform(-10, 10, (n, 3))
+        w = rng.choice([0.125, 0.25, 0.5, 1.0], n)
+    xyz, w = xyz.astype(np.float32), w.astype(np.float32)
+    want = M.fps_sequential(xyz, m, weights=w)
+    assert want[0] == M.first_pick(n, M.opt_log2s(n), w)
+    regs = _regions(n, nreg, rng, True, xyz)
+    for kw in (dict(seed=3), dict(seed=4, greedy=True, depth=4), dict(seed=5, greedy=True, depth=0, hide_duplicates=True),
+               dict(seed=6, delay=3, depth=2)):
+        assert M.run(xyz, m, regs, weights=w, kernel_keys=kernel_keys, **kw) == want, (case, kw)
